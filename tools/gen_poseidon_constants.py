@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Derive the Poseidon-Goldilocks (width 12, x^7, 4+22+4 rounds) constant tables.
+
+Inputs (data): tools/poseidon_round_constants.txt (30x12 round constants) and the
+MDS definition circ/diag (reference: plonky2/src/hash/poseidon_goldilocks.rs:24-25).
+
+Everything else -- the "fast partial round" tables the reference hard-codes at
+plonky2/src/hash/poseidon_goldilocks.rs:27-215 -- is DERIVED here from first principles
+(Poseidon paper, appendix B: push the partial-round constants through the linear layer
+and factor the MDS matrix into one dense pre-matrix and 22 sparse matrices), then checked
+against (a) naive-vs-fast permutation equality and (b) the four known-answer vectors of
+plonky2/src/hash/poseidon_goldilocks.rs:449-485.
+
+Output: a C/HIP include file with the tables, shared by oracle/ and the HIP kernels.
+
+Usage: python tools/gen_poseidon_constants.py [out.h]
+"""
+import os
+import sys
+
+P = 0xFFFFFFFF00000001
+W = 12
+HALF_FULL = 4
+N_PARTIAL = 22
+N_ROUNDS = 2 * HALF_FULL + N_PARTIAL
+MDS_CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
+MDS_DIAG = [8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_round_constants():
+    rows = []
+    with open(os.path.join(HERE, "poseidon_round_constants.txt")) as f:
+        for line in f:
+            line = line.strip()
+            if not line or line.startswith("#"):
+                continue
+            rows.append([int(x, 16) for x in line.split()])
+    assert len(rows) == N_ROUNDS and all(len(r) == W for r in rows)
+    return rows
+
+
+def mds_matrix():
+    # column-vector convention: out[r] = sum_c M[r][c] * in[c]; M[r][c] = circ[(c-r) mod 12] (+diag)
+    M = [[MDS_CIRC[(c - r) % W] % P for c in range(W)] for r in range(W)]
+    for r in range(W):
+        M[r][r] = (M[r][r] + MDS_DIAG[r]) % P
+    return M
+
+
+def mat_mul(A, B):
+    n, k, m = len(A), len(B), len(B[0])
+    return [[sum(A[i][t] * B[t][j] for t in range(k)) % P for j in range(m)] for i in range(n)]
+
+
+def mat_vec(A, v):
+    return [sum(a * b for a, b in zip(row, v)) % P for row in A]
+
+
+def mat_inv(A):
+    n = len(A)
+    M = [row[:] + [1 if i == j else 0 for j in range(n)] for i, row in enumerate(A)]
+    for c in range(n):
+        piv = next(r for r in range(c, n) if M[r][c] % P)
+        M[c], M[piv] = M[piv], M[c]
+        inv = pow(M[c][c], P - 2, P)
+        M[c] = [x * inv % P for x in M[c]]
+        for r in range(n):
+            if r != c and M[r][c]:
+                f = M[r][c]
+                M[r] = [(x - f * y) % P for x, y in zip(M[r], M[c])]
+    return [row[n:] for row in M]
+
+
+def derive(rc):
+    M = mds_matrix()
+    Minv = mat_inv(M)
+    # --- constants: push partial-round constants backwards through M ---------------------
+    # naive: x <- M * S(x + c_r); fast: y <- M * (S(y) + k_r e0), with y_0 = x_0 + first
+    part = rc[HALF_FULL:HALF_FULL + N_PARTIAL]
+    delta = [0] * W
+    ks = [0] * N_PARTIAL
+    for r in range(N_PARTIAL - 2, -1, -1):
+        v = mat_vec(Minv, [(d - c) % P for d, c in zip(delta, part[r + 1])])
+        ks[r] = (-v[0]) % P
+        delta = [0] + v[1:]
+    first = [(c - d) % P for c, d in zip(part[0], delta)]
+    # k was defined through x+c = y+delta with delta_{r+1} = c_{r+1} + M(delta_r - k_r e0); the
+    # sign convention is validated numerically below (naive == fast).
+    # --- matrices: M N_{R-1} ... M N_0 = A_{R-1} N_{R-1} ... A_0 N_0 D_0 ----------------------
+    D_hat = [[1 if i == j else 0 for j in range(W - 1)] for i in range(W - 1)]
+    v_row = M[0][1:]
+    rows_v = [None] * N_PARTIAL   # multiplies s[1..] into out[0]
+    cols_w = [None] * N_PARTIAL   # multiplies s[0] into out[1..]
+    Mhat = [row[1:] for row in M[1:]]
+    wcol = [M[i][0] for i in range(1, W)]
+    for r in range(N_PARTIAL - 1, -1, -1):
+        P_hat = mat_mul(D_hat, Mhat)
+        pw = mat_vec(D_hat, wcol)
+        P_hat_inv = mat_inv(P_hat)
+        # row vector v^T * P_hat^{-1}
+        rows_v[r] = [sum(v_row[t] * P_hat_inv[t][j] for t in range(W - 1)) % P for j in range(W - 1)]
+        cols_w[r] = pw
+        D_hat = P_hat
+    init = D_hat  # out[1..] = init * in[1..]
+    return dict(first=first, ks=ks, rows_v=rows_v, cols_w=cols_w, init=init, M=M)
+
+
+def sbox(x):
+    return pow(x, 7, P)
+
+
+def perm_naive(state, rc, M):
+    s = [x % P for x in state]
+    r = 0
+    for _ in range(HALF_FULL):
+        s = mat_vec(M, [sbox((a + c) % P) for a, c in zip(s, rc[r])]); r += 1
+    for _ in range(N_PARTIAL):
+        s = [(a + c) % P for a, c in zip(s, rc[r])]
+        s[0] = sbox(s[0])
+        s = mat_vec(M, s); r += 1
+    for _ in range(HALF_FULL):
+        s = mat_vec(M, [sbox((a + c) % P) for a, c in zip(s, rc[r])]); r += 1
+    return s
+
+
+def perm_fast(state, rc, T):
+    M = T["M"]
+    s = [x % P for x in state]
+    r = 0
+    for _ in range(HALF_FULL):
+        s = mat_vec(M, [sbox((a + c) % P) for a, c in zip(s, rc[r])]); r += 1
+    s = [(a + c) % P for a, c in zip(s, T["first"])]
+    s = [s[0]] + mat_vec(T["init"], s[1:])
+    m00 = M[0][0]
+    for i in range(N_PARTIAL):
+        s0 = (sbox(s[0]) + T["ks"][i]) % P
+        d = (s0 * m00 + sum(a * b for a, b in zip(s[1:], T["rows_v"][i]))) % P
+        s = [d] + [(s[j] + s0 * T["cols_w"][i][j - 1]) % P for j in range(1, W)]
+    r += N_PARTIAL
+    for _ in range(HALF_FULL):
+        s = mat_vec(M, [sbox((a + c) % P) for a, c in zip(s, rc[r])]); r += 1
+    return s
+
+
+# Known-answer vectors: plonky2/src/hash/poseidon_goldilocks.rs:449-485 (data).
+KATS = [
+    ([0] * 12,
+     [0x3c18a9786cb0b359, 0xc4055e3364a246c3, 0x7953db0ab48808f4, 0xc71603f33a1144ca,
+      0xd7709673896996dc, 0x46a84e87642f44ed, 0xd032648251ee0b3c, 0x1c687363b207df62,
+      0xdf8565563e8045fe, 0x40f5b37ff4254dae, 0xd070f637b431067c, 0x1792b1c4342109d7]),
+    (list(range(12)),
+     [0xd64e1e3efc5b8e9e, 0x53666633020aaa47, 0xd40285597c6a8825, 0x613a4f81e81231d2,
+      0x414754bfebd051f0, 0xcb1f8980294a023f, 0x6eb2a9e4d54a9d0f, 0x1902bc3af467e056,
+      0xf045d5eafdc6021f, 0xe4150f77caaa3be5, 0xc9bfd01d39b50cce, 0x5c0a27fcb0e1459b]),
+    ([P - 1] * 12,
+     [0xbe0085cfc57a8357, 0xd95af71847d05c09, 0xcf55a13d33c1c953, 0x95803a74f4530e82,
+      0xfcd99eb30a135df1, 0xe095905e913a3029, 0xde0392461b42919b, 0x7d3260e24e81d031,
+      0x10d3d0465d9deaa0, 0xa87571083dfc2a47, 0xe18263681e9958f8, 0xe28e96f1ae5e60d3]),
+    ([0x8ccbbbea4fe5d2b7, 0xc2af59ee9ec49970, 0x90f7e1a9e658446a, 0xdcc0630a3ab8b1b8,
+      0x7ff8256bca20588c, 0x5d99a7ca0c44ecfb, 0x48452b17a70fbee3, 0xeb09d654690b6c88,
+      0x4a55d3a39c676a88, 0xc0407a38d2285139, 0xa234bac9356386d1, 0xe1633f2bad98a52f],
+     [0xa89280105650c4ec, 0xab542d53860d12ed, 0x5704148e9ccab94f, 0xd3a826d4b62da9f5,
+      0x8a7a6ca87892574f, 0xc7017e1cad1a674e, 0x1f06668922318e34, 0xa3b203bc8102676f,
+      0xfcc781b0ce382bf2, 0x934c69ff3ed14ba5, 0x504688a5996e8f13, 0x401f3f2ed524a2ba]),
+]
+
+
+def emit(path, rc, T):
+    def arr(name, vals, per_line=4):
+        out = ["static const uint64_t %s[%d] = {" % (name, len(vals))]
+        for i in range(0, len(vals), per_line):
+            out.append("    " + ", ".join("0x%016xULL" % v for v in vals[i:i + per_line]) + ",")
+        out.append("};")
+        return "\n".join(out)
+
+    flat = lambda rows: [x for row in rows for x in row]
+    txt = [
+        "// GENERATED by tools/gen_poseidon_constants.py -- do not edit.",
+        "// Poseidon over Goldilocks, width 12, rate 8, x^7, 4+22+4 rounds.",
+        "// Round constants are data (tools/poseidon_round_constants.txt); the partial-round tables are",
+        "// derived by the generator and validated against the reference's known-answer vectors.",
+        "#pragma once",
+        "#include <stdint.h>",
+        "#define POSEIDON_WIDTH 12",
+        "#define POSEIDON_RATE 8",
+        "#define POSEIDON_HALF_FULL_ROUNDS 4",
+        "#define POSEIDON_PARTIAL_ROUNDS 22",
+        arr("POSEIDON_RC", flat(rc)),
+        arr("POSEIDON_MDS_CIRC", MDS_CIRC, 12),
+        arr("POSEIDON_MDS_DIAG", MDS_DIAG, 12),
+        "// added to the whole state before the partial rounds",
+        arr("POSEIDON_PARTIAL_FIRST_RC", T["first"]),
+        "// added to state[0] after its s-box in partial round i",
+        arr("POSEIDON_PARTIAL_RC", T["ks"]),
+        "// dense 11x11 pre-matrix, row-major [in-1][out-1]: out[c] = sum_r in[r] * INIT[r-1][c-1]",
+        arr("POSEIDON_PARTIAL_INIT", flat([[T["init"][c][r] for c in range(W - 1)] for r in range(W - 1)])),
+        "// per partial round: out[0] = m00*s0 + sum_i s[i]*ROW[r][i-1]",
+        arr("POSEIDON_PARTIAL_ROW", flat(T["rows_v"])),
+        "// per partial round: out[i] = s[i] + s0*COL[r][i-1]",
+        arr("POSEIDON_PARTIAL_COL", flat(T["cols_w"])),
+        "",
+    ]
+    with open(path, "w") as f:
+        f.write("\n".join(txt))
+
+
+def main():
+    rc = load_round_constants()
+    T = derive(rc)
+    import random
+    rnd = random.Random(1)
+    tests = [k[0] for k in KATS] + [[rnd.randrange(P) for _ in range(W)] for _ in range(4)]
+    for t in tests:
+        assert perm_naive(t, rc, T["M"]) == perm_fast(t, rc, T), "fast != naive"
+    for inp, out in KATS:
+        assert perm_fast(inp, rc, T) == out, "KAT mismatch"
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(
+        HERE, "..", "plonky2_demo_amd", "csrc", "poseidon_constants.h")
+    emit(out, rc, T)
+    print("ok: naive==fast on %d inputs, 4 KATs pass; wrote %s" % (len(tests), os.path.normpath(out)))
+    return T
+
+
+if __name__ == "__main__":
+    main()
