@@ -1,0 +1,139 @@
+/*
+ * plonky2_mi355x.h -- C ABI of libplonky2_mi355x.so, the MI355X (gfx950) backend for the prove() hot path
+ * of the Plonky2 matrix-multiplication demo circuit.
+ *
+ * The reference (Lain-Iwakuro/Plonky2-Demo, a plonky2 fork) has no FFI seam; this header cuts one at the
+ * `PolynomialBatch` type (plonky2/src/fri/oracle.rs:30-37) and at the prover-side consumers that reach
+ * into it (plonky2/src/plonk/prover.rs:102-329).  Every entry point names the reference interface it
+ * replaces.  INTEGRATION.md shows the Rust `extern "C"` block and the patch to the call sites.
+ *
+ * Conventions
+ *  - A field element is a little-endian uint64_t, layout-compatible with `#[repr(transparent)]
+ *    GoldilocksField(pub u64)` (field/src/goldilocks_field.rs:23-25).  Inputs may be non-canonical
+ *    (any u64); every output is canonical (< p = 2^64 - 2^32 + 1).
+ *  - An extension element (F_p[X]/(X^2-7)) is two consecutive uint64_t: (a0, a1)
+ *    (field/src/extension/quadratic.rs:14).  A digest (HashOut) is four uint64_t
+ *    (plonky2/src/hash/hash_types.rs:20-24).
+ *  - `h_` pointers are host memory owned by the caller; `d_` pointers are device (HIP) memory on the
+ *    context's device.  Opaque handles own device memory and are released with their *_free.
+ *  - All functions return GL_OK (0) or a GL_ERR_* code and never unwind; gl_last_error() gives the
+ *    text for the calling thread.  The reference panics on shape errors (oracle.rs:114,
+ *    merkle_tree.rs:137-143, fft.rs:175-181); here they are GL_ERR_ARG.
+ *  - A gl_ctx is bound to one device and one HIP stream; calls on one ctx are issued in order on that
+ *    stream.  Different ctxs may be used concurrently from different threads.
+ *  - There is NO CPU fallback: without a HIP device every compute entry point fails with GL_ERR_HIP.
+ */
+#ifndef PLONKY2_MI355X_H
+#define PLONKY2_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GL_OK 0
+#define GL_ERR_ARG 1          /* bad shape / null pointer / unsupported size          */
+#define GL_ERR_HIP 2          /* HIP runtime error (no device, OOM, launch failure)   */
+#define GL_ERR_UNSUPPORTED 3  /* e.g. blinding != 0 (zero-knowledge salts)            */
+#define GL_ERR_ZETA_IN_SUBGROUP 4 /* prover.rs:280-283: opening point lies in H       */
+#define GL_ERR_INTERNAL 5
+
+typedef struct gl_ctx gl_ctx;
+typedef struct gl_batch gl_batch;      /* device-resident PolynomialBatch (fri/oracle.rs:30-37)  */
+typedef struct gl_merkle gl_merkle;    /* device-resident MerkleTree (hash/merkle_tree.rs:39-55) */
+
+/* ---- context ------------------------------------------------------------------------------------ */
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL to let
+ * the context create its own non-blocking stream. */
+int gl_ctx_create(int device, void* stream, gl_ctx** out);
+void gl_ctx_destroy(gl_ctx* ctx);
+int gl_ctx_synchronize(gl_ctx* ctx);
+/* scratch used between the two NTT passes (elements); default 2^24 (128 MiB). */
+int gl_ctx_set_scratch_elems(gl_ctx* ctx, size_t elems);
+const char* gl_last_error(void);
+/* device memory helpers so that a host language needs no HIP binding of its own */
+int gl_dev_alloc(gl_ctx* ctx, size_t bytes, void** d_out);
+int gl_dev_free(gl_ctx* ctx, void* d_ptr);
+int gl_copy_h2d(gl_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int gl_copy_d2h(gl_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* synchronises */
+
+/* ---- field micro-kernels (tests; replace nothing on the path by themselves) ----------------------
+ * op: 0 add, 1 sub, 2 mul, 3 neg(a), 4 inverse(a), 5 canonicalise(a), 6 a + b*c, 7 a * 2^(b mod 192)
+ * (field/src/goldilocks_field.rs:186-274,138-142).  out may alias a. */
+int gl_field_op(gl_ctx* ctx, int op, const uint64_t* d_a, const uint64_t* d_b, const uint64_t* d_c,
+                uint64_t* d_out, size_t n);
+/* op: 0 add, 1 sub, 2 mul, 3 inverse on interleaved (a0,a1) pairs (extension/quadratic.rs:143-193) */
+int gl_ext_op(gl_ctx* ctx, int op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n);
+
+/* ---- NTT family: d_data is [batch][2^log_n], transformed in place, natural order in and out ------ */
+/* fft_with_options(poly, None, root_table) (field/src/fft.rs:56-65): values[i] = P(w^i) */
+int gl_ntt_forward(gl_ctx* ctx, uint64_t* d_data, uint32_t log_n, uint32_t batch);
+/* ifft_with_options (field/src/fft.rs:72-95) */
+int gl_ntt_inverse(gl_ctx* ctx, uint64_t* d_data, uint32_t log_n, uint32_t batch);
+/* PolynomialCoeffs::coset_fft (field/src/polynomial/mod.rs:276-295): evaluations on shift*H */
+int gl_ntt_coset_forward(gl_ctx* ctx, uint64_t* d_data, uint32_t log_n, uint32_t batch, uint64_t shift);
+/* PolynomialValues::coset_ifft (field/src/polynomial/mod.rs:58-70) */
+int gl_ntt_coset_inverse(gl_ctx* ctx, uint64_t* d_data, uint32_t log_n, uint32_t batch, uint64_t shift);
+/* p.lde(rate_bits).coset_fft_with_options(F::coset_shift(), Some(rate_bits), table)
+ * (plonky2/src/fri/oracle.rs:111-118): d_coeffs [batch][2^log_n] -> d_out [batch][2^(log_n+rate_bits)],
+ * natural order (index i <-> point 7*w^i). */
+int gl_ntt_coset_lde(gl_ctx* ctx, const uint64_t* d_coeffs, uint32_t log_n, uint32_t rate_bits,
+                     uint32_t batch, uint64_t* d_out);
+/* host-buffer convenience (H2D + transform + D2H): direction 0 forward, 1 inverse */
+int gl_fft_host(gl_ctx* ctx, uint64_t* h_data, uint32_t log_n, uint32_t batch, int inverse);
+
+/* ---- Poseidon / hashing --------------------------------------------------------------------------*/
+/* Poseidon::poseidon (plonky2/src/hash/poseidon.rs:598-609) on `count` 12-word states, in place */
+int gl_poseidon_permute(gl_ctx* ctx, uint64_t* d_states, size_t count);
+/* Hasher::hash_or_noop (plonky2/src/plonk/config.rs:55-66) of `count` rows of `len` elements,
+ * row-major d_rows[count][len] -> d_out[count][4] */
+int gl_hash_rows(gl_ctx* ctx, const uint64_t* d_rows, size_t count, size_t len, uint64_t* d_out);
+
+/* ---- Merkle tree ---------------------------------------------------------------------------------*/
+/* MerkleTree::new(leaves, cap_height) (plonky2/src/hash/merkle_tree.rs:135-165) for row-major host
+ * leaves h_leaves[num_leaves][leaf_len]; the tree keeps a device copy of the leaves. */
+int gl_merkle_new(gl_ctx* ctx, const uint64_t* h_leaves, size_t num_leaves, size_t leaf_len,
+                  uint32_t cap_height, gl_merkle** out);
+/* field `cap` (merkle_tree.rs:54): h_out[2^cap_height][4] */
+int gl_merkle_cap(const gl_merkle* t, uint64_t* h_out);
+/* MerkleTree::prove (merkle_tree.rs:171-207): siblings bottom-up, h_out[log2(n) - cap_height][4] */
+int gl_merkle_prove(const gl_merkle* t, size_t leaf_index, uint64_t* h_out, uint32_t* n_siblings);
+void gl_merkle_free(gl_merkle* t);
+
+/* ---- PolynomialBatch -----------------------------------------------------------------------------*/
+/* PolynomialBatch::from_values(values, rate_bits, blinding, cap_height, timing, fft_root_table)
+ * (plonky2/src/fri/oracle.rs:43-66).  h_cols[c] points at the n = 2^k values of polynomial c.
+ * blinding must be 0 (GL_ERR_UNSUPPORTED otherwise).  Keeps coefficients, LDE values and all Merkle
+ * digests device-resident. */
+int gl_batch_from_values(gl_ctx* ctx, const uint64_t* const* h_cols, size_t ncols, size_t n,
+                         uint32_t rate_bits, uint32_t blinding, uint32_t cap_height, gl_batch** out);
+/* PolynomialBatch::from_coeffs (plonky2/src/fri/oracle.rs:68-98) */
+int gl_batch_from_coeffs(gl_ctx* ctx, const uint64_t* const* h_cols, size_t ncols, size_t n,
+                         uint32_t rate_bits, uint32_t blinding, uint32_t cap_height, gl_batch** out);
+/* same, from a device-resident column-major matrix d_cols[ncols][n]; is_values selects from_values */
+int gl_batch_from_device(gl_ctx* ctx, const uint64_t* d_cols, size_t ncols, size_t n, uint32_t rate_bits,
+                         uint32_t cap_height, int is_values, gl_batch** out);
+/* field `merkle_tree.cap` (used at prover.rs:164,225,273,319-321): h_out[2^cap_height][4] */
+int gl_batch_cap(const gl_batch* b, uint64_t* h_out);
+/* merkle_tree.get(i) (merkle_tree.rs:167-169): the leaf at Merkle index i, h_out[ncols] */
+int gl_batch_get_leaf(const gl_batch* b, size_t leaf_index, uint64_t* h_out);
+/* PolynomialBatch::get_lde_values(index, step) (oracle.rs:128-133), h_out[ncols] */
+int gl_batch_get_lde_values(const gl_batch* b, size_t index, size_t step, uint64_t* h_out);
+/* merkle_tree.prove(i) (merkle_tree.rs:171-207) */
+int gl_batch_prove(const gl_batch* b, size_t leaf_index, uint64_t* h_out, uint32_t* n_siblings);
+/* field `polynomials` (oracle.rs:32): h_out[ncols][n] coefficients */
+int gl_batch_coeffs(const gl_batch* b, uint64_t* h_out);
+/* all LDE values in natural order, column-major h_out[ncols][n << rate_bits] (index i <-> 7*w^i) */
+int gl_batch_lde(const gl_batch* b, uint64_t* h_out);
+size_t gl_batch_ncols(const gl_batch* b);
+size_t gl_batch_degree(const gl_batch* b);
+const uint64_t* gl_batch_dev_coeffs(const gl_batch* b);   /* d [ncols][n]  */
+const uint64_t* gl_batch_dev_lde(const gl_batch* b);      /* d [ncols][N]  */
+void gl_batch_free(gl_batch* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLONKY2_MI355X_H */

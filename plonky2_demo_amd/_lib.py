@@ -1,0 +1,89 @@
+"""ctypes binding of libplonky2_mi355x.so (the C ABI declared in include/plonky2_mi355x.h).
+
+The library is HIP-only: importing this module works without a GPU (so that symbol/ABI checks can run on a
+CPU box), but creating a context fails loudly when no MI355X is visible.  There is no CPU fallback and the
+CPU oracle under oracle/ is never imported from here.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplonky2_mi355x.so")
+
+GL_OK = 0
+ERRORS = {1: "GL_ERR_ARG", 2: "GL_ERR_HIP", 3: "GL_ERR_UNSUPPORTED", 4: "GL_ERR_ZETA_IN_SUBGROUP", 5: "GL_ERR_INTERNAL"}
+
+
+class Plonky2Mi355xError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("%s: %s" % (ERRORS.get(code, "error %d" % code), text))
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libplonky2_mi355x.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C plonky2_demo_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    return ctypes.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_vp = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+c_u32 = ctypes.c_uint32
+c_u64 = ctypes.c_uint64
+c_int = ctypes.c_int
+
+# name -> (restype, argtypes); every symbol include/plonky2_mi355x.h declares must appear here
+SIGNATURES = {
+    "gl_ctx_create": (c_int, [c_int, c_vp, ctypes.POINTER(c_vp)]),
+    "gl_ctx_destroy": (None, [c_vp]),
+    "gl_ctx_synchronize": (c_int, [c_vp]),
+    "gl_ctx_set_scratch_elems": (c_int, [c_vp, c_sz]),
+    "gl_last_error": (ctypes.c_char_p, []),
+    "gl_dev_alloc": (c_int, [c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "gl_dev_free": (c_int, [c_vp, c_vp]),
+    "gl_copy_h2d": (c_int, [c_vp, c_vp, c_vp, c_sz]),
+    "gl_copy_d2h": (c_int, [c_vp, c_vp, c_vp, c_sz]),
+    "gl_field_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_sz]),
+    "gl_ext_op": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_sz]),
+    "gl_ntt_forward": (c_int, [c_vp, c_vp, c_u32, c_u32]),
+    "gl_ntt_inverse": (c_int, [c_vp, c_vp, c_u32, c_u32]),
+    "gl_ntt_coset_forward": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u64]),
+    "gl_ntt_coset_inverse": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u64]),
+    "gl_ntt_coset_lde": (c_int, [c_vp, c_vp, c_u32, c_u32, c_u32, c_vp]),
+    "gl_fft_host": (c_int, [c_vp, c_vp, c_u32, c_u32, c_int]),
+    "gl_poseidon_permute": (c_int, [c_vp, c_vp, c_sz]),
+    "gl_hash_rows": (c_int, [c_vp, c_vp, c_sz, c_sz, c_vp]),
+    "gl_merkle_new": (c_int, [c_vp, c_vp, c_sz, c_sz, c_u32, ctypes.POINTER(c_vp)]),
+    "gl_merkle_cap": (c_int, [c_vp, c_vp]),
+    "gl_merkle_prove": (c_int, [c_vp, c_sz, c_vp, ctypes.POINTER(c_u32)]),
+    "gl_merkle_free": (None, [c_vp]),
+    "gl_batch_from_values": (c_int, [c_vp, ctypes.POINTER(c_vp), c_sz, c_sz, c_u32, c_u32, c_u32, ctypes.POINTER(c_vp)]),
+    "gl_batch_from_coeffs": (c_int, [c_vp, ctypes.POINTER(c_vp), c_sz, c_sz, c_u32, c_u32, c_u32, ctypes.POINTER(c_vp)]),
+    "gl_batch_from_device": (c_int, [c_vp, c_vp, c_sz, c_sz, c_u32, c_u32, c_int, ctypes.POINTER(c_vp)]),
+    "gl_batch_cap": (c_int, [c_vp, c_vp]),
+    "gl_batch_get_leaf": (c_int, [c_vp, c_sz, c_vp]),
+    "gl_batch_get_lde_values": (c_int, [c_vp, c_sz, c_sz, c_vp]),
+    "gl_batch_prove": (c_int, [c_vp, c_sz, c_vp, ctypes.POINTER(c_u32)]),
+    "gl_batch_coeffs": (c_int, [c_vp, c_vp]),
+    "gl_batch_lde": (c_int, [c_vp, c_vp]),
+    "gl_batch_ncols": (c_sz, [c_vp]),
+    "gl_batch_degree": (c_sz, [c_vp]),
+    "gl_batch_dev_coeffs": (c_vp, [c_vp]),
+    "gl_batch_dev_lde": (c_vp, [c_vp]),
+    "gl_batch_free": (None, [c_vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)   # AttributeError here = the .so does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(status):
+    if status != GL_OK:
+        raise Plonky2Mi355xError(status, (lib.gl_last_error() or b"").decode())

@@ -1,0 +1,343 @@
+"""Host-side mirror of the reference's operator interfaces for the hot path (numpy in / numpy out).
+
+Everything here is plumbing over the C ABI: no arithmetic happens in Python.  Arrays are uint64, an
+extension element is a pair, a digest is four words.  Reference lines are cited per function.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+GOLDILOCKS_ORDER = 0xFFFFFFFF00000001   # field/src/goldilocks_field.rs:152
+COSET_SHIFT = 7                          # field/src/types.rs:437-439, goldilocks_field.rs:80
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _log2_strict(n):
+    lg = int(n).bit_length() - 1
+    if n <= 0 or (1 << lg) != n:
+        raise ValueError("length %d is not a power of two" % n)   # util/src/lib.rs:35-40 panics
+    return lg
+
+
+class DeviceBuffer:
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        check(lib.gl_dev_alloc(ctx.handle, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = _u64(arr)
+        assert arr.nbytes <= self.nbytes
+        check(lib.gl_copy_h2d(self.ctx.handle, self.ptr, _p(arr), arr.nbytes))
+        return self
+
+    def download(self, shape):
+        out = np.empty(shape, dtype=np.uint64)
+        assert out.nbytes <= self.nbytes
+        check(lib.gl_copy_d2h(self.ctx.handle, _p(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            check(lib.gl_dev_free(self.ctx.handle, self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per (device, stream).  `stream` may be a raw hipStream_t (int), e.g.
+    torch.cuda.current_stream().cuda_stream, so that torch events bracket the library's kernels."""
+
+    def __init__(self, device=0, stream=None):
+        h = ctypes.c_void_p()
+        check(lib.gl_ctx_create(int(device), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h)))
+        self.handle = h.value
+        self.device = device
+
+    def synchronize(self):
+        check(lib.gl_ctx_synchronize(self.handle))
+
+    def set_scratch_elems(self, elems):
+        check(lib.gl_ctx_set_scratch_elems(self.handle, int(elems)))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def close(self):
+        if self.handle:
+            lib.gl_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def default_context():
+    global _default
+    if _default is None:
+        _default = Context(0)
+    return _default
+
+
+def _ctx(ctx):
+    return ctx if ctx is not None else default_context()
+
+
+# ---------------------------------------------------------------------------------------------- field
+def field_op(op, a, b=None, c=None, ctx=None):
+    """op: 0 add 1 sub 2 mul 3 neg 4 inverse 5 canonicalise 6 a+b*c 7 a*2^(b%192)."""
+    ctx = _ctx(ctx)
+    a = _u64(a)
+    n = a.size
+    da = ctx.alloc(max(8, a.nbytes)).upload(a)
+    db = ctx.alloc(max(8, a.nbytes)).upload(_u64(b)) if b is not None else None
+    dc = ctx.alloc(max(8, a.nbytes)).upload(_u64(c)) if c is not None else None
+    do = ctx.alloc(max(8, a.nbytes))
+    check(lib.gl_field_op(ctx.handle, op, da.ptr, db.ptr if db else None, dc.ptr if dc else None, do.ptr, n))
+    return do.download(a.shape)
+
+
+def ext_op(op, a, b=None, ctx=None):
+    ctx = _ctx(ctx)
+    a = _u64(a)
+    n = a.size // 2
+    da = ctx.alloc(max(8, a.nbytes)).upload(a)
+    db = ctx.alloc(max(8, a.nbytes)).upload(_u64(b)) if b is not None else None
+    do = ctx.alloc(max(8, a.nbytes))
+    check(lib.gl_ext_op(ctx.handle, op, da.ptr, db.ptr if db else None, do.ptr, n))
+    return do.download(a.shape)
+
+
+# ------------------------------------------------------------------------------------------------ NTT
+def _transform(kind, arr, shift=None, ctx=None):
+    ctx = _ctx(ctx)
+    arr = _u64(arr)
+    single = arr.ndim == 1
+    a2 = arr.reshape(1, -1) if single else arr
+    batch, n = a2.shape
+    lg = _log2_strict(n)
+    d = ctx.alloc(max(8, a2.nbytes)).upload(a2)
+    if kind == "fft":
+        check(lib.gl_ntt_forward(ctx.handle, d.ptr, lg, batch))
+    elif kind == "ifft":
+        check(lib.gl_ntt_inverse(ctx.handle, d.ptr, lg, batch))
+    elif kind == "coset_fft":
+        check(lib.gl_ntt_coset_forward(ctx.handle, d.ptr, lg, batch, shift))
+    elif kind == "coset_ifft":
+        check(lib.gl_ntt_coset_inverse(ctx.handle, d.ptr, lg, batch, shift))
+    out = d.download(a2.shape)
+    return out.reshape(-1) if single else out
+
+
+def fft(coeffs, ctx=None):
+    """field::fft::fft (field/src/fft.rs:52-65): values[i] = P(w^i); [n] or [batch][n]."""
+    return _transform("fft", coeffs, ctx=ctx)
+
+
+def ifft(values, ctx=None):
+    """field::fft::ifft (field/src/fft.rs:67-95)."""
+    return _transform("ifft", values, ctx=ctx)
+
+
+def coset_fft(coeffs, shift=COSET_SHIFT, ctx=None):
+    """PolynomialCoeffs::coset_fft (field/src/polynomial/mod.rs:276-295)."""
+    return _transform("coset_fft", coeffs, shift=shift, ctx=ctx)
+
+
+def coset_ifft(values, shift=COSET_SHIFT, ctx=None):
+    """PolynomialValues::coset_ifft (field/src/polynomial/mod.rs:58-70)."""
+    return _transform("coset_ifft", values, shift=shift, ctx=ctx)
+
+
+def lde_onto_coset(coeffs, rate_bits, ctx=None):
+    """coeffs.lde(rate_bits).coset_fft_with_options(7, Some(rate_bits)) (plonky2/src/fri/oracle.rs:111-118)."""
+    ctx = _ctx(ctx)
+    c2 = _u64(coeffs)
+    single = c2.ndim == 1
+    if single:
+        c2 = c2.reshape(1, -1)
+    batch, n = c2.shape
+    lg = _log2_strict(n)
+    src = ctx.alloc(max(8, c2.nbytes)).upload(c2)
+    dst = ctx.alloc(c2.nbytes << rate_bits)
+    check(lib.gl_ntt_coset_lde(ctx.handle, src.ptr, lg, rate_bits, batch, dst.ptr))
+    out = dst.download((batch, n << rate_bits))
+    return out.reshape(-1) if single else out
+
+
+# ------------------------------------------------------------------------------------------- hashing
+def poseidon(states, ctx=None):
+    """Poseidon::poseidon (plonky2/src/hash/poseidon.rs:598-609) on [12] or [count][12]."""
+    ctx = _ctx(ctx)
+    s = _u64(states)
+    if s.shape[-1] != 12:
+        raise ValueError("Poseidon state width is 12")
+    d = ctx.alloc(s.nbytes).upload(s)
+    check(lib.gl_poseidon_permute(ctx.handle, d.ptr, s.size // 12))
+    return d.download(s.shape)
+
+
+def hash_or_noop(rows, ctx=None):
+    """Hasher::hash_or_noop (plonky2/src/plonk/config.rs:55-66) per row of [count][len] -> [count][4]."""
+    ctx = _ctx(ctx)
+    r = _u64(rows)
+    single = r.ndim == 1
+    if single:
+        r = r.reshape(1, -1)
+    count, ln = r.shape
+    if ln == 0:
+        return np.zeros((4,) if single else (count, 4), dtype=np.uint64)
+    d = ctx.alloc(max(8, r.nbytes)).upload(r)
+    o = ctx.alloc(max(32, count * 32))
+    check(lib.gl_hash_rows(ctx.handle, d.ptr, count, ln, o.ptr))
+    out = o.download((count, 4))
+    return out[0] if single else out
+
+
+class MerkleTree:
+    """plonky2::hash::merkle_tree::MerkleTree (merkle_tree.rs:39-207) with device-resident digests."""
+
+    def __init__(self, leaves, cap_height, ctx=None):
+        self.ctx = _ctx(ctx)
+        l2 = _u64(leaves)
+        if l2.ndim != 2:
+            raise ValueError("leaves must be [num_leaves][leaf_len]")
+        self.num_leaves, self.leaf_len = l2.shape
+        self.cap_height = cap_height
+        self.leaves = l2
+        h = ctypes.c_void_p()
+        check(lib.gl_merkle_new(self.ctx.handle, _p(l2), self.num_leaves, self.leaf_len, cap_height, ctypes.byref(h)))
+        self.handle = h.value
+
+    @property
+    def cap(self):
+        out = np.empty((1 << self.cap_height, 4), dtype=np.uint64)
+        check(lib.gl_merkle_cap(self.handle, _p(out)))
+        return out
+
+    def get(self, i):
+        return self.leaves[i]
+
+    def prove(self, leaf_index):
+        n = ctypes.c_uint32()
+        out = np.empty((64, 4), dtype=np.uint64)
+        check(lib.gl_merkle_prove(self.handle, leaf_index, _p(out), ctypes.byref(n)))
+        return out[: n.value].copy()
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.gl_merkle_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class PolynomialBatch:
+    """plonky2::fri::oracle::PolynomialBatch (fri/oracle.rs:30-133), device-resident."""
+
+    def __init__(self, handle, ctx, rate_bits, cap_height):
+        self.handle, self.ctx, self.rate_bits, self.cap_height = handle, ctx, rate_bits, cap_height
+        self.ncols = lib.gl_batch_ncols(handle)
+        self.degree = lib.gl_batch_degree(handle)
+        self.degree_log = _log2_strict(self.degree)
+
+    @classmethod
+    def _from_host(cls, fn, cols, rate_bits, blinding, cap_height, ctx):
+        ctx = _ctx(ctx)
+        cols = [_u64(c) for c in cols]
+        if not cols:
+            raise ValueError("empty batch")
+        n = cols[0].size
+        if any(c.size != n for c in cols):
+            raise ValueError("Polynomial degrees inconsistent")   # oracle.rs:114
+        ptrs = (ctypes.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+        h = ctypes.c_void_p()
+        check(fn(ctx.handle, ptrs, len(cols), n, rate_bits, 1 if blinding else 0, cap_height, ctypes.byref(h)))
+        return cls(h.value, ctx, rate_bits, cap_height)
+
+    @classmethod
+    def from_values(cls, values, rate_bits, blinding, cap_height, ctx=None):
+        """PolynomialBatch::from_values (fri/oracle.rs:43-66)."""
+        return cls._from_host(lib.gl_batch_from_values, values, rate_bits, blinding, cap_height, ctx)
+
+    @classmethod
+    def from_coeffs(cls, polynomials, rate_bits, blinding, cap_height, ctx=None):
+        """PolynomialBatch::from_coeffs (fri/oracle.rs:68-98)."""
+        return cls._from_host(lib.gl_batch_from_coeffs, polynomials, rate_bits, blinding, cap_height, ctx)
+
+    @classmethod
+    def from_device(cls, d_ptr, ncols, n, rate_bits, cap_height, is_values, ctx=None):
+        ctx = _ctx(ctx)
+        h = ctypes.c_void_p()
+        check(lib.gl_batch_from_device(ctx.handle, d_ptr, ncols, n, rate_bits, cap_height, 1 if is_values else 0, ctypes.byref(h)))
+        return cls(h.value, ctx, rate_bits, cap_height)
+
+    @property
+    def cap(self):
+        out = np.empty((1 << self.cap_height, 4), dtype=np.uint64)
+        check(lib.gl_batch_cap(self.handle, _p(out)))
+        return out
+
+    @property
+    def polynomials(self):
+        out = np.empty((self.ncols, self.degree), dtype=np.uint64)
+        check(lib.gl_batch_coeffs(self.handle, _p(out)))
+        return out
+
+    def lde_values(self):
+        out = np.empty((self.ncols, self.degree << self.rate_bits), dtype=np.uint64)
+        check(lib.gl_batch_lde(self.handle, _p(out)))
+        return out
+
+    def get_leaf(self, i):
+        out = np.empty(self.ncols, dtype=np.uint64)
+        check(lib.gl_batch_get_leaf(self.handle, i, _p(out)))
+        return out
+
+    def get_lde_values(self, index, step):
+        """PolynomialBatch::get_lde_values (fri/oracle.rs:128-133)."""
+        out = np.empty(self.ncols, dtype=np.uint64)
+        check(lib.gl_batch_get_lde_values(self.handle, index, step, _p(out)))
+        return out
+
+    def prove(self, leaf_index):
+        n = ctypes.c_uint32()
+        out = np.empty((64, 4), dtype=np.uint64)
+        check(lib.gl_batch_prove(self.handle, leaf_index, _p(out), ctypes.byref(n)))
+        return out[: n.value].copy()
+
+    def free(self):
+        if self.handle:
+            lib.gl_batch_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,90 @@
+// Library context: one per (device, stream).  Owns twiddle / power tables and scratch memory so that
+// no entry point allocates or synchronises on its hot path (graph-capture friendly after warm-up).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+#include "gl64.cuh"
+#include "../../include/plonky2_mi355x.h"
+
+extern thread_local std::string g_gl_last_error;
+int gl_fail(int code, const char* what, const char* file, int line);
+
+#define GL_CHECK_HIP(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) return gl_fail(GL_ERR_HIP, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define GL_REQUIRE(cond, code, msg)                                      \
+    do {                                                                 \
+        if (!(cond)) return gl_fail(code, msg, __FILE__, __LINE__);      \
+    } while (0)
+#define GL_TRY(expr)                 \
+    do {                             \
+        int _s = (expr);             \
+        if (_s != GL_OK) return _s;  \
+    } while (0)
+
+static const gl_t GL_MULT_GENERATOR = 7;                          // field/src/goldilocks_field.rs:80
+static const gl_t GL_POW2_GENERATOR = 1753635133440165772ULL;     // field/src/goldilocks_field.rs:87
+
+inline gl_t gl_host_root_of_unity(unsigned lg) {                   // field/src/types.rs:268-272
+    gl_t r = GL_POW2_GENERATOR;
+    for (unsigned i = lg; i < 32; i++) r = gl_sqr(r);
+    return gl_canon(r);
+}
+inline gl_t gl_host_inverse_2exp(unsigned e) { return GL_P - ((GL_P - 1) >> e); }   // types.rs:227-266
+
+struct GlPowTable {
+    gl_t* lo = nullptr;   // base^j, j < 2048
+    gl_t* hi = nullptr;   // scale * base^(2048 j)
+    uint32_t hi_len = 0;
+};
+
+struct gl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    gl_t* tw_local[2] = {nullptr, nullptr};                       // w_4096^e forward / inverse
+    std::map<std::pair<gl_t, gl_t>, GlPowTable> pow_tables;       // (base, scale) -> table
+    gl_t* scratch = nullptr;
+    size_t scratch_elems = 0;
+    size_t scratch_target = size_t(1) << 24;                      // 128 MiB: stays Infinity-Cache resident
+    // small pinned staging for D2H of caps / openings / query rows
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    gl_t* dev_small = nullptr;                                    // 1 MiB device staging
+    size_t dev_small_bytes = 0;
+
+    int activate();
+    int ensure_scratch(size_t elems);
+    int ensure_pinned(size_t bytes);
+    int ensure_dev_small(size_t bytes);
+    int get_pow_table(gl_t base, gl_t scale, uint32_t hi_len, GlPowTable* out);
+    // small read-only index tables (Merkle leaf element offsets, ...) cached by content
+    std::map<std::vector<uint64_t>, uint64_t*> offset_tables;
+    int get_offsets_table(const uint64_t* host, size_t len, const uint64_t** d_out);
+};
+
+// ---- NTT launcher (ntt.hip) ---------------------------------------------------------------------------
+// dst[b][k] = post_const * post_shift^k * sum_i (pre_shift^i * src[b][i]) * w^(+-ik),  i < n_in, k < 2^lgN
+// pre_shift / post_shift == 0 mean "no scaling".  src may equal dst.  Output canonical.
+int gl_ntt_run(gl_ctx* ctx, const gl_t* src, uint64_t src_stride, uint32_t n_in, gl_t* dst, uint64_t dst_stride,
+               uint32_t lgN, uint32_t batch, bool inverse, gl_t pre_shift, gl_t post_shift, gl_t post_const);
+
+// ---- Merkle (merkle.hip) ------------------------------------------------------------------------------
+struct GlMerkle {
+    uint32_t lg_leaves = 0, cap_height = 0, leaf_len = 0;
+    gl_t* digests = nullptr;                 // levels concatenated, level l at level_off[l] (in digests)
+    std::vector<uint64_t> level_off;         // in units of digests (4 x u64)
+    uint64_t total_digests = 0;
+    gl_t* level_ptr(uint32_t l) const { return digests + 4 * level_off[l]; }
+    uint32_t num_levels() const { return lg_leaves - cap_height + 1; }
+};
+// leaf r (natural order) has elements base[offsets[e] + r], e < leaf_len; it is leaf bitrev(r) of the tree
+int gl_merkle_build(gl_ctx* ctx, const gl_t* base, const uint64_t* host_offsets, uint32_t leaf_len,
+                    uint32_t lg_leaves, uint32_t cap_height, GlMerkle* out);
+void gl_merkle_release(GlMerkle* m);

@@ -1,0 +1,347 @@
+// NTT launchers, context management and the NTT / field entry points of the C ABI.
+#include "context.hpp"
+#include "ntt.cuh"
+#include <cstdio>
+#include <cstring>
+
+thread_local std::string g_gl_last_error;
+
+int gl_fail(int code, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s (%s:%d)", what, file, line);
+    g_gl_last_error = buf;
+    return code;
+}
+
+// ------------------------------------------------------------------------------------------ context
+int gl_ctx::activate() {
+    int cur = -1;
+    GL_CHECK_HIP(hipGetDevice(&cur));
+    if (cur != device) GL_CHECK_HIP(hipSetDevice(device));
+    return GL_OK;
+}
+int gl_ctx::ensure_scratch(size_t elems) {
+    if (elems <= scratch_elems) return GL_OK;
+    if (scratch) { GL_CHECK_HIP(hipStreamSynchronize(stream)); GL_CHECK_HIP(hipFree(scratch)); scratch = nullptr; scratch_elems = 0; }
+    GL_CHECK_HIP(hipMalloc((void**)&scratch, elems * sizeof(gl_t)));
+    scratch_elems = elems;
+    return GL_OK;
+}
+int gl_ctx::ensure_pinned(size_t bytes) {
+    if (bytes <= pinned_bytes) return GL_OK;
+    if (pinned) { GL_CHECK_HIP(hipStreamSynchronize(stream)); GL_CHECK_HIP(hipHostFree(pinned)); pinned = nullptr; pinned_bytes = 0; }
+    size_t sz = bytes < (1u << 20) ? (1u << 20) : bytes;
+    GL_CHECK_HIP(hipHostMalloc(&pinned, sz, hipHostMallocDefault));
+    pinned_bytes = sz;
+    return GL_OK;
+}
+int gl_ctx::ensure_dev_small(size_t bytes) {
+    if (bytes <= dev_small_bytes) return GL_OK;
+    if (dev_small) { GL_CHECK_HIP(hipStreamSynchronize(stream)); GL_CHECK_HIP(hipFree(dev_small)); dev_small = nullptr; dev_small_bytes = 0; }
+    size_t sz = bytes < (1u << 20) ? (1u << 20) : bytes;
+    GL_CHECK_HIP(hipMalloc((void**)&dev_small, sz));
+    dev_small_bytes = sz;
+    return GL_OK;
+}
+int gl_ctx::get_pow_table(gl_t base, gl_t scale, uint32_t hi_len, GlPowTable* out) {
+    auto key = std::make_pair(base, scale);
+    auto it = pow_tables.find(key);
+    if (it != pow_tables.end() && it->second.hi_len >= hi_len) { *out = it->second; return GL_OK; }
+    GlPowTable t;
+    if (hi_len < 1) hi_len = 1;
+    t.hi_len = hi_len;
+    const uint32_t lo_len = 1u << NTT_SPLIT_LOG;
+    GL_CHECK_HIP(hipMalloc((void**)&t.lo, (size_t)(lo_len + hi_len) * sizeof(gl_t)));
+    t.hi = t.lo + lo_len;
+    uint32_t m = lo_len > hi_len ? lo_len : hi_len;
+    hipLaunchKernelGGL(ntt_power_table, dim3((m + 255) / 256), dim3(256), 0, stream, base, scale, t.lo, t.hi, hi_len);
+    GL_CHECK_HIP(hipGetLastError());
+    // an older, shorter table for the same key stays allocated until the context dies (it may be in flight)
+    pow_tables[key] = t;
+    *out = t;
+    return GL_OK;
+}
+
+int gl_ctx::get_offsets_table(const uint64_t* host, size_t len, const uint64_t** d_out) {
+    std::vector<uint64_t> key(host, host + len);
+    auto it = offset_tables.find(key);
+    if (it != offset_tables.end()) { *d_out = it->second; return GL_OK; }
+    uint64_t* d = nullptr;
+    GL_CHECK_HIP(hipMalloc((void**)&d, len * sizeof(uint64_t)));
+    GL_CHECK_HIP(hipMemcpyAsync(d, host, len * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    GL_CHECK_HIP(hipStreamSynchronize(stream));   // first use only
+    offset_tables[key] = d;
+    *d_out = d;
+    return GL_OK;
+}
+
+extern "C" int gl_ctx_create(int device, void* stream, gl_ctx** out) {
+    GL_REQUIRE(out != nullptr, GL_ERR_ARG, "gl_ctx_create: out is null");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) return gl_fail(GL_ERR_HIP, "no HIP device available (this library has no CPU fallback)", __FILE__, __LINE__);
+    GL_REQUIRE(device >= 0 && device < count, GL_ERR_ARG, "gl_ctx_create: bad device index");
+    GL_CHECK_HIP(hipSetDevice(device));
+    gl_ctx* c = new gl_ctx();
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { GL_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    const uint32_t len = 1u << NTT_LOCAL_MAX_LOG;
+    for (int dir = 0; dir < 2; dir++) {
+        GL_CHECK_HIP(hipMalloc((void**)&c->tw_local[dir], len * sizeof(gl_t)));
+        gl_t w = gl_host_root_of_unity(NTT_LOCAL_MAX_LOG);
+        if (dir) w = gl_canon(gl_inv(w));
+        hipLaunchKernelGGL(ntt_root_table, dim3(len / 256), dim3(256), 0, c->stream, w, c->tw_local[dir], len);
+    }
+    GL_CHECK_HIP(hipGetLastError());
+    *out = c;
+    return GL_OK;
+}
+extern "C" void gl_ctx_destroy(gl_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int d = 0; d < 2; d++) if (c->tw_local[d]) (void)hipFree(c->tw_local[d]);
+    for (auto& kv : c->pow_tables) (void)hipFree(kv.second.lo);
+    for (auto& kv : c->offset_tables) (void)hipFree(kv.second);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->dev_small) (void)hipFree(c->dev_small);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" int gl_ctx_synchronize(gl_ctx* c) {
+    GL_REQUIRE(c, GL_ERR_ARG, "null ctx");
+    GL_TRY(c->activate());
+    GL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return GL_OK;
+}
+extern "C" int gl_ctx_set_scratch_elems(gl_ctx* c, size_t elems) {
+    GL_REQUIRE(c && elems >= (size_t(1) << NTT_TILE_LOG), GL_ERR_ARG, "bad scratch size");
+    c->scratch_target = elems;
+    return GL_OK;
+}
+extern "C" const char* gl_last_error(void) { return g_gl_last_error.c_str(); }
+extern "C" int gl_dev_alloc(gl_ctx* c, size_t bytes, void** d_out) {
+    GL_REQUIRE(c && d_out, GL_ERR_ARG, "null argument");
+    GL_TRY(c->activate());
+    GL_CHECK_HIP(hipMalloc(d_out, bytes ? bytes : 8));
+    return GL_OK;
+}
+extern "C" int gl_dev_free(gl_ctx* c, void* d_ptr) {
+    GL_REQUIRE(c, GL_ERR_ARG, "null ctx");
+    GL_TRY(c->activate());
+    GL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    GL_CHECK_HIP(hipFree(d_ptr));
+    return GL_OK;
+}
+extern "C" int gl_copy_h2d(gl_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+    GL_REQUIRE(c && d_dst && h_src, GL_ERR_ARG, "null argument");
+    GL_TRY(c->activate());
+    GL_CHECK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    GL_CHECK_HIP(hipStreamSynchronize(c->stream));   // pageable source must not be reused before the copy lands
+    return GL_OK;
+}
+extern "C" int gl_copy_d2h(gl_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+    GL_REQUIRE(c && h_dst && d_src, GL_ERR_ARG, "null argument");
+    GL_TRY(c->activate());
+    GL_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    GL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return GL_OK;
+}
+
+// ---------------------------------------------------------------------------------------- launchers
+template <int LOGL, bool INV>
+static int launch_col(gl_ctx* c, const NttPassParams& p, dim3 grid) {
+    constexpr int T = 1 << (NTT_TILE_LOG - LOGL);
+    constexpr size_t lds = (size_t)(1 << LOGL) * (T + 1) * sizeof(gl_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GL_CHECK_HIP(hipFuncSetAttribute((const void*)ntt_col_pass<LOGL, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ntt_col_pass<LOGL, INV>), grid, dim3(NTT_THREADS), lds, c->stream, p);
+    GL_CHECK_HIP(hipGetLastError());
+    return GL_OK;
+}
+template <int LOGL, bool INV>
+static int launch_row(gl_ctx* c, const NttPassParams& p, dim3 grid) {
+    constexpr int T = 1 << (NTT_TILE_LOG - LOGL);
+    constexpr size_t lds = (size_t)(1 << LOGL) * (T + 1) * sizeof(gl_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GL_CHECK_HIP(hipFuncSetAttribute((const void*)ntt_row_pass<LOGL, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ntt_row_pass<LOGL, INV>), grid, dim3(NTT_THREADS), lds, c->stream, p);
+    GL_CHECK_HIP(hipGetLastError());
+    return GL_OK;
+}
+
+#define NTT_DISPATCH(fn, logl, inv, ...)                                             \
+    switch (logl) {                                                                  \
+        case 1: return (inv) ? fn<1, true>(__VA_ARGS__) : fn<1, false>(__VA_ARGS__);   \
+        case 2: return (inv) ? fn<2, true>(__VA_ARGS__) : fn<2, false>(__VA_ARGS__);   \
+        case 3: return (inv) ? fn<3, true>(__VA_ARGS__) : fn<3, false>(__VA_ARGS__);   \
+        case 4: return (inv) ? fn<4, true>(__VA_ARGS__) : fn<4, false>(__VA_ARGS__);   \
+        case 5: return (inv) ? fn<5, true>(__VA_ARGS__) : fn<5, false>(__VA_ARGS__);   \
+        case 6: return (inv) ? fn<6, true>(__VA_ARGS__) : fn<6, false>(__VA_ARGS__);   \
+        case 7: return (inv) ? fn<7, true>(__VA_ARGS__) : fn<7, false>(__VA_ARGS__);   \
+        case 8: return (inv) ? fn<8, true>(__VA_ARGS__) : fn<8, false>(__VA_ARGS__);   \
+        case 9: return (inv) ? fn<9, true>(__VA_ARGS__) : fn<9, false>(__VA_ARGS__);   \
+        case 10: return (inv) ? fn<10, true>(__VA_ARGS__) : fn<10, false>(__VA_ARGS__); \
+        case 11: return (inv) ? fn<11, true>(__VA_ARGS__) : fn<11, false>(__VA_ARGS__); \
+        case 12: return (inv) ? fn<12, true>(__VA_ARGS__) : fn<12, false>(__VA_ARGS__); \
+        default: return gl_fail(GL_ERR_ARG, "unsupported local NTT size", __FILE__, __LINE__); \
+    }
+
+static int dispatch_col(gl_ctx* c, int logl, bool inv, const NttPassParams& p, dim3 grid) { NTT_DISPATCH(launch_col, logl, inv, c, p, grid) }
+static int dispatch_row(gl_ctx* c, int logl, bool inv, const NttPassParams& p, dim3 grid) { NTT_DISPATCH(launch_row, logl, inv, c, p, grid) }
+
+__global__ void ntt_copy_canon(const gl_t* src, uint64_t src_stride, gl_t* dst, uint64_t dst_stride, uint32_t batch, gl_t f) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) dst[b * dst_stride] = gl_canon(gl_mul(src[b * src_stride], f));
+}
+
+int gl_ntt_run(gl_ctx* c, const gl_t* src, uint64_t src_stride, uint32_t n_in, gl_t* dst, uint64_t dst_stride,
+               uint32_t lgN, uint32_t batch, bool inverse, gl_t pre_shift, gl_t post_shift, gl_t post_const) {
+    GL_REQUIRE(c && src && dst, GL_ERR_ARG, "gl_ntt_run: null argument");
+    GL_REQUIRE(lgN <= 2 * NTT_LOCAL_MAX_LOG && lgN <= 32, GL_ERR_ARG, "gl_ntt_run: transform too large");
+    if (batch == 0) return GL_OK;
+    GL_TRY(c->activate());
+    const uint64_t N = uint64_t(1) << lgN;
+    GL_REQUIRE(n_in >= 1 && n_in <= N, GL_ERR_ARG, "gl_ntt_run: bad input length");
+    if (lgN == 0) {
+        hipLaunchKernelGGL(ntt_copy_canon, dim3((batch + 255) / 256), dim3(256), 0, c->stream, src, src_stride, dst, dst_stride, batch, post_const);
+        GL_CHECK_HIP(hipGetLastError());
+        return GL_OK;
+    }
+    NttPassParams p;
+    memset(&p, 0, sizeof p);
+    p.tw_local = c->tw_local[inverse ? 1 : 0];
+    p.post_const = 1;
+    GlPowTable pre, post, tw;
+    if (pre_shift) GL_TRY(c->get_pow_table(gl_canon(pre_shift), 1, (n_in + (1u << NTT_SPLIT_LOG) - 1) >> NTT_SPLIT_LOG, &pre));
+    if (post_shift) GL_TRY(c->get_pow_table(gl_canon(post_shift), gl_canon(post_const), (uint32_t)((N + (1u << NTT_SPLIT_LOG) - 1) >> NTT_SPLIT_LOG), &post));
+
+    if (lgN <= NTT_LOCAL_MAX_LOG) {
+        p.src = src; p.dst = dst; p.src_stride = src_stride; p.dst_stride = dst_stride;
+        p.batch = batch; p.lgN1 = 0; p.lgN2 = lgN; p.n_in = n_in;
+        if (pre_shift) { p.pre_lo = pre.lo; p.pre_hi = pre.hi; }
+        if (post_shift) { p.post_lo = post.lo; p.post_hi = post.hi; } else p.post_const = gl_canon(post_const);
+        const uint32_t T = 1u << (NTT_TILE_LOG - lgN);
+        return dispatch_row(c, (int)lgN, inverse, p, dim3((batch + T - 1) / T, 1));
+    }
+    const uint32_t lgN1 = lgN / 2, lgN2 = lgN - lgN1;
+    gl_t w = gl_host_root_of_unity(lgN);
+    if (inverse) w = gl_canon(gl_inv(w));
+    GL_TRY(c->get_pow_table(w, 1, (uint32_t)(N >> NTT_SPLIT_LOG), &tw));
+    size_t want = c->scratch_target > N ? c->scratch_target : N;
+    if (want > (size_t)batch * N) want = (size_t)batch * N;
+    GL_TRY(c->ensure_scratch(want));
+    const uint32_t chunk_max = (uint32_t)(c->scratch_elems >> lgN);
+    const uint32_t TA = 1u << (NTT_TILE_LOG - lgN1), TB = 1u << (NTT_TILE_LOG - lgN2);
+    for (uint32_t b0 = 0; b0 < batch; b0 += chunk_max) {
+        const uint32_t nb = (batch - b0) < chunk_max ? (batch - b0) : chunk_max;
+        NttPassParams a = p;
+        a.src = src + (uint64_t)b0 * src_stride; a.src_stride = src_stride;
+        a.dst = c->scratch; a.dst_stride = N;
+        a.batch = nb; a.lgN1 = lgN1; a.lgN2 = lgN2; a.n_in = n_in;
+        a.tw_lo = tw.lo; a.tw_hi = tw.hi;
+        if (pre_shift) { a.pre_lo = pre.lo; a.pre_hi = pre.hi; }
+        GL_TRY(dispatch_col(c, (int)lgN1, inverse, a, dim3((1u << lgN2) / TA, nb)));
+        NttPassParams r = p;
+        r.src = c->scratch; r.src_stride = N;
+        r.dst = dst + (uint64_t)b0 * dst_stride; r.dst_stride = dst_stride;
+        r.batch = nb; r.lgN1 = lgN1; r.lgN2 = lgN2; r.n_in = (uint32_t)N;
+        if (post_shift) { r.post_lo = post.lo; r.post_hi = post.hi; } else r.post_const = gl_canon(post_const);
+        GL_TRY(dispatch_row(c, (int)lgN2, inverse, r, dim3((1u << lgN1) / TB, nb)));
+    }
+    return GL_OK;
+}
+
+// ------------------------------------------------------------------------------------- C ABI: NTTs
+extern "C" int gl_ntt_forward(gl_ctx* c, uint64_t* d, uint32_t log_n, uint32_t batch) {
+    return gl_ntt_run(c, d, uint64_t(1) << log_n, 1u << log_n, d, uint64_t(1) << log_n, log_n, batch, false, 0, 0, 1);
+}
+extern "C" int gl_ntt_inverse(gl_ctx* c, uint64_t* d, uint32_t log_n, uint32_t batch) {
+    return gl_ntt_run(c, d, uint64_t(1) << log_n, 1u << log_n, d, uint64_t(1) << log_n, log_n, batch, true, 0, 0,
+                      gl_host_inverse_2exp(log_n));
+}
+extern "C" int gl_ntt_coset_forward(gl_ctx* c, uint64_t* d, uint32_t log_n, uint32_t batch, uint64_t shift) {
+    GL_REQUIRE(gl_canon(shift) != 0, GL_ERR_ARG, "coset shift must be non-zero");
+    return gl_ntt_run(c, d, uint64_t(1) << log_n, 1u << log_n, d, uint64_t(1) << log_n, log_n, batch, false, shift, 0, 1);
+}
+extern "C" int gl_ntt_coset_inverse(gl_ctx* c, uint64_t* d, uint32_t log_n, uint32_t batch, uint64_t shift) {
+    GL_REQUIRE(gl_canon(shift) != 0, GL_ERR_ARG, "coset shift must be non-zero");
+    return gl_ntt_run(c, d, uint64_t(1) << log_n, 1u << log_n, d, uint64_t(1) << log_n, log_n, batch, true, 0,
+                      gl_canon(gl_inv(shift)), gl_host_inverse_2exp(log_n));
+}
+extern "C" int gl_ntt_coset_lde(gl_ctx* c, const uint64_t* d_coeffs, uint32_t log_n, uint32_t rate_bits, uint32_t batch, uint64_t* d_out) {
+    GL_REQUIRE(log_n + rate_bits <= 2 * NTT_LOCAL_MAX_LOG, GL_ERR_ARG, "LDE too large");
+    return gl_ntt_run(c, d_coeffs, uint64_t(1) << log_n, 1u << log_n, d_out, uint64_t(1) << (log_n + rate_bits),
+                      log_n + rate_bits, batch, false, GL_MULT_GENERATOR, 0, 1);
+}
+extern "C" int gl_fft_host(gl_ctx* c, uint64_t* h_data, uint32_t log_n, uint32_t batch, int inverse) {
+    GL_REQUIRE(c && h_data, GL_ERR_ARG, "null argument");
+    GL_TRY(c->activate());
+    size_t bytes = ((size_t)batch << log_n) * sizeof(gl_t);
+    gl_t* d = nullptr;
+    GL_CHECK_HIP(hipMalloc((void**)&d, bytes ? bytes : 8));
+    int st = gl_copy_h2d(c, d, h_data, bytes);
+    if (st == GL_OK) st = inverse ? gl_ntt_inverse(c, d, log_n, batch) : gl_ntt_forward(c, d, log_n, batch);
+    if (st == GL_OK) st = gl_copy_d2h(c, h_data, d, bytes);
+    (void)hipFree(d);
+    return st;
+}
+
+// ----------------------------------------------------------------------------- C ABI: field kernels
+__global__ void k_field_op(int op, const gl_t* a, const gl_t* b, const gl_t* cc, gl_t* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gl_t r = 0;
+    switch (op) {
+        case 0: r = gl_add(a[i], b[i]); break;
+        case 1: r = gl_sub(a[i], b[i]); break;
+        case 2: r = gl_mul(a[i], b[i]); break;
+        case 3: r = gl_neg(a[i]); break;
+        case 4: r = gl_inv(a[i]); break;
+        case 5: r = a[i]; break;
+        case 6: r = gl_mul_add(a[i], b[i], cc[i]); break;
+        case 7: r = gl_mul_2exp(a[i], (unsigned)(b[i] % 192)); break;
+    }
+    out[i] = gl_canon(r);
+}
+__global__ void k_ext_op(int op, const gl_t* a, const gl_t* b, gl_t* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gl2_t x = gl2_make(a[2 * i], a[2 * i + 1]), y = gl2_make(0, 0), r = gl2_make(0, 0);
+    if (b) y = gl2_make(b[2 * i], b[2 * i + 1]);
+    switch (op) {
+        case 0: r = gl2_add(x, y); break;
+        case 1: r = gl2_sub(x, y); break;
+        case 2: r = gl2_mul(x, y); break;
+        case 3: r = gl2_inv(x); break;
+    }
+    r = gl2_canon(r);
+    out[2 * i] = r.a; out[2 * i + 1] = r.b;
+}
+extern "C" int gl_field_op(gl_ctx* c, int op, const uint64_t* a, const uint64_t* b, const uint64_t* cc, uint64_t* out, size_t n) {
+    GL_REQUIRE(c && a && out && op >= 0 && op <= 7, GL_ERR_ARG, "gl_field_op: bad argument");
+    GL_REQUIRE((op == 3 || op == 4 || op == 5) || b, GL_ERR_ARG, "gl_field_op: b is null");
+    GL_REQUIRE(op != 6 || cc, GL_ERR_ARG, "gl_field_op: c is null");
+    if (!n) return GL_OK;
+    GL_TRY(c->activate());
+    hipLaunchKernelGGL(k_field_op, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, op, a, b, cc, out, n);
+    GL_CHECK_HIP(hipGetLastError());
+    return GL_OK;
+}
+extern "C" int gl_ext_op(gl_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    GL_REQUIRE(c && a && out && op >= 0 && op <= 3, GL_ERR_ARG, "gl_ext_op: bad argument");
+    GL_REQUIRE(op == 3 || b, GL_ERR_ARG, "gl_ext_op: b is null");
+    if (!n) return GL_OK;
+    GL_TRY(c->activate());
+    hipLaunchKernelGGL(k_ext_op, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, op, a, b, out, n);
+    GL_CHECK_HIP(hipGetLastError());
+    return GL_OK;
+}

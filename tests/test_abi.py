@@ -1,0 +1,44 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/plonky2_mi355x.h declares, and the
+product path fails loudly (no CPU fallback) when no GPU is present."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "plonky2_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from plonky2_demo_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(_lib.lib, n), "libplonky2_mi355x.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "binding table misses %s" % n
+    assert set(_lib.SIGNATURES) <= set(names), "binding table has symbols the header does not declare"
+
+
+def test_product_never_touches_the_oracle():
+    """The shipped path must not import, link, include or dlopen anything under oracle/."""
+    pkg = os.path.join(ROOT, "plonky2_demo_amd")
+    bad = re.compile(r"liboracle|oracle_lib|#include\s*[\"<][^\">]*oracle/|^\s*(import|from)\s+oracle|gl_field\.hpp|gl_batch\.hpp", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".cpp", ".h", ".inc")) or f == "Makefile":
+                src = open(os.path.join(dirpath, f)).read()
+                assert not bad.search(src), "%s references the oracle" % f
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import plonky2_demo_amd as p
+    with pytest.raises(p.Plonky2Mi355xError):
+        p.Context(0)

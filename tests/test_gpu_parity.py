@@ -1,0 +1,221 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI against the CPU oracle, the committed golden
+fixtures and size-independent properties.  Bit-exact: all values are canonical u64."""
+import numpy as np
+import pytest
+
+from oracle_lib import P, rand_field
+
+pytestmark = pytest.mark.gpu
+
+
+def ints(a):
+    return [int(x) for x in np.asarray(a).reshape(-1)]
+
+
+# ------------------------------------------------------------------------------------------------ field
+def test_field_ops_edge_grid(gpu, orc, golden):
+    p, ctx = gpu
+    from plonky2_demo_amd import api
+    g = golden["field_grid"]
+    a = np.array([x for x in g for _ in g], dtype=np.uint64)
+    b = np.array([y for _ in g for y in g], dtype=np.uint64)
+    c = np.roll(a, 7)
+    for op in (0, 1, 2):
+        assert (api.field_op(op, a, b) == orc.field_op(op, a, b)).all(), op
+    assert (api.field_op(6, a, b, c) == orc.field_op(6, a, b, c)).all()
+    ga = np.array(g, dtype=np.uint64)
+    assert (api.field_op(3, ga) == orc.field_op(3, ga)).all()
+    assert (api.field_op(5, ga) == orc.field_op(5, ga)).all()
+    nz = np.array([x for x in g if x % P], dtype=np.uint64)
+    assert (api.field_op(4, nz) == orc.field_op(4, nz)).all()
+    # x * 2^e for all 192 exponents on the grid (shift-twiddles of the NTT butterflies)
+    e = np.arange(192, dtype=np.uint64)
+    xs = np.repeat(ga, 192)
+    es = np.tile(e, len(g))
+    got = api.field_op(7, xs, es)
+    assert ints(got) == [int(x) * pow(2, int(k), P) % P for x, k in zip(xs, es)]
+
+
+def test_field_ops_random(gpu, orc):
+    from plonky2_demo_amd import api
+    a = np.random.default_rng(1).integers(0, 2**64, size=1 << 16, dtype=np.uint64)   # non-canonical inputs allowed
+    b = np.random.default_rng(2).integers(0, 2**64, size=1 << 16, dtype=np.uint64)
+    c = np.random.default_rng(3).integers(0, 2**64, size=1 << 16, dtype=np.uint64)
+    for op in (0, 1, 2):
+        assert (api.field_op(op, a, b) == orc.field_op(op, a, b)).all(), op
+    assert (api.field_op(6, a, b, c) == orc.field_op(6, a, b, c)).all()
+    ea, eb = rand_field(4, 4096), rand_field(5, 4096)
+    for op in (0, 1, 2):
+        assert (api.ext_op(op, ea, eb) == orc.ext_op(op, ea, eb)).all(), op
+    assert (api.ext_op(3, ea) == orc.ext_op(3, ea)).all()
+
+
+# -------------------------------------------------------------------------------------------------- NTT
+def test_fft_reference_test_case(gpu, golden):
+    p, ctx = gpu
+    c = np.array(golden["fft256"]["coeffs"], dtype=np.uint64)
+    v = p.fft(c)
+    assert ints(v) == golden["fft256"]["values"]          # field/src/fft.rs:234-235
+    assert (p.ifft(v) == c).all()                          # :237-243
+    for case in golden["ntt_model"]:
+        cc = np.array(case["coeffs"], dtype=np.uint64)
+        assert ints(p.fft(cc)) == case["values"]
+        assert ints(p.coset_fft(cc, 7)) == case["coset7"]
+    m = golden["lde_model"]
+    assert ints(p.lde_onto_coset(np.array(m["coeffs"], dtype=np.uint64), m["rate_bits"])) == m["values"]
+
+
+@pytest.mark.parametrize("lg", list(range(0, 17)))
+def test_ntt_matches_oracle_all_sizes(gpu, orc, lg):
+    p, ctx = gpu
+    batch = 5 if lg <= 12 else 3          # ragged batches: not a multiple of the tile's polynomial count
+    x = rand_field(100 + lg, (batch, 1 << lg))
+    f = p.fft(x)
+    assert (f == orc.fft(x)).all()
+    assert (p.ifft(x) == orc.ifft(x)).all()
+    assert (p.ifft(f) == x).all()
+    assert (p.coset_fft(x, 7) == orc.coset_fft(x, 7)).all()
+    assert (p.coset_ifft(x, 7) == orc.coset_ifft(x, 7)).all()
+    s = 0x123456789ABCDEF % P
+    assert (p.coset_fft(x, s) == orc.coset_fft(x, s)).all()
+
+
+@pytest.mark.parametrize("lg,rate", [(0, 3), (1, 3), (3, 3), (5, 1), (9, 3), (10, 3), (12, 3), (13, 2), (15, 3)])
+def test_coset_lde_matches_oracle(gpu, orc, lg, rate):
+    p, ctx = gpu
+    x = rand_field(200 + lg, (3, 1 << lg))
+    assert (p.lde_onto_coset(x, rate) == orc.lde(x, rate, threads=4)).all()
+
+
+def test_ntt_non_canonical_input(gpu, orc):
+    p, ctx = gpu
+    x = np.random.default_rng(7).integers(0, 2**64, size=(2, 1 << 13), dtype=np.uint64)
+    assert (p.fft(x) == orc.fft(x)).all()
+    assert (p.ifft(x) == orc.ifft(x)).all()
+
+
+def test_ntt_2_20_against_oracle_and_round_trip(gpu, orc):
+    # BASELINE config 2: 2^20-point forward + inverse, bit-exact vs field::fft on B = 2; properties on B = 8
+    p, ctx = gpu
+    x = rand_field(20, (2, 1 << 20))
+    f = p.fft(x)
+    assert (f == orc.fft(x)).all()
+    assert (p.ifft(f) == x).all()
+    assert (p.ifft(x) == orc.ifft(x)).all()
+    y = rand_field(21, (8, 1 << 20))
+    fy = p.fft(y)
+    assert (p.ifft(fy) == y).all()
+    # linearity: fft(a) + fft(b) == fft(a + b)
+    s = orc.field_op(0, y[0], y[1])
+    assert (orc.field_op(0, fy[0], fy[1]) == p.fft(s)).all()
+    # first output is the sum of the coefficients
+    for b in range(2):
+        assert int(fy[b][0]) == sum(int(v) for v in y[b]) % P
+
+
+def test_ntt_large_sizes_round_trip(gpu, orc):
+    p, ctx = gpu
+    for lg in (17, 18, 19, 21, 22):
+        x = rand_field(300 + lg, (2, 1 << lg))
+        f = p.fft(x)
+        assert (p.ifft(f) == x).all(), lg
+        assert int(f[1][0]) == sum(int(v) for v in x[1]) % P
+        if lg <= 18:
+            assert (f == orc.fft(x)).all()
+
+
+def test_ntt_chunked_batches(gpu, orc):
+    # more polynomials than fit the inter-pass scratch: exercises the chunk loop
+    p, ctx = gpu
+    ctx.set_scratch_elems(1 << 15)
+    try:
+        x = rand_field(77, (11, 1 << 14))
+        assert (p.fft(x) == orc.fft(x)).all()
+    finally:
+        ctx.set_scratch_elems(1 << 24)
+
+
+# --------------------------------------------------------------------------------------- Poseidon/Merkle
+def test_poseidon_known_answers(gpu, orc, golden):
+    p, ctx = gpu
+    for kat in golden["poseidon_kats"] + golden["poseidon_model"]:
+        assert ints(p.poseidon(np.array(kat["input"], dtype=np.uint64))) == kat["output"]
+    r = np.random.default_rng(11).integers(0, 2**64, size=(4096, 12), dtype=np.uint64)
+    assert (p.poseidon(r) == orc.poseidon(r)).all()
+
+
+@pytest.mark.parametrize("ln", [1, 3, 4, 5, 7, 8, 9, 16, 17, 32, 84, 135])
+def test_hash_or_noop_rows(gpu, orc, ln):
+    p, ctx = gpu
+    rows = np.random.default_rng(ln).integers(0, 2**64, size=(33, ln), dtype=np.uint64)
+    got = p.hash_or_noop(rows)
+    for i in range(33):
+        assert (got[i] == orc.hash_or_noop(rows[i])).all()
+
+
+def test_merkle_tree_golden_and_oracle(gpu, orc, golden):
+    p, ctx = gpu
+    m = golden["merkle_model"]
+    leaves = np.array(m["leaves"], dtype=np.uint64)
+    for t in m["trees"]:
+        tree = p.MerkleTree(leaves, t["cap_height"])
+        assert tree.cap.tolist() == t["cap"]
+        for idx, sib in t["paths"].items():
+            assert tree.prove(int(idx)).tolist() == sib
+    s = golden["merkle_short"]
+    assert p.MerkleTree(np.array(s["leaves"], dtype=np.uint64), s["cap_height"]).cap.tolist() == s["cap"]
+    # merkle_tree.rs:253-281: 256 x 7 random leaves, every path verifies to the cap, cap heights 1 and 8
+    leaves = rand_field(9, (256, 7))
+    for cap_height in (0, 1, 8):
+        tree = p.MerkleTree(leaves, cap_height)
+        ot = orc.merkle(leaves, cap_height)
+        assert (tree.cap == ot.cap).all()
+        for i in range(0, 256, 5):
+            sib = tree.prove(i)
+            assert (sib == ot.prove(i)).all()
+            assert orc.merkle_verify(leaves[i], i, tree.cap, sib)
+    with pytest.raises(p.Plonky2Mi355xError):
+        p.MerkleTree(leaves, 9)        # merkle_tree.rs:137-143
+    # one-leaf tree and single-element leaves
+    one = rand_field(10, (1, 5))
+    assert (p.MerkleTree(one, 0).cap == orc.merkle(one, 0).cap).all()
+
+
+# -------------------------------------------------------------------------------------- PolynomialBatch
+def test_polynomial_batch_golden(gpu, golden):
+    p, ctx = gpu
+    m = golden["batch_model"]
+    b = p.PolynomialBatch.from_values(np.array(m["values"], dtype=np.uint64), m["rate_bits"], False, m["cap_height"])
+    assert b.polynomials.tolist() == m["coeffs"]
+    assert b.lde_values().tolist() == m["lde"]
+    assert b.cap.tolist() == m["cap"]
+    assert b.get_leaf(13).tolist() == m["leaf_13"]
+    m9 = golden["batch_model9"]
+    b9 = p.PolynomialBatch.from_values(np.array(m9["values"], dtype=np.uint64), m9["rate_bits"], False, m9["cap_height"])
+    assert b9.cap.tolist() == m9["cap"]
+    assert b9.prove(37).tolist() == m9["path_37"]
+    with pytest.raises(p.Plonky2Mi355xError):
+        p.PolynomialBatch.from_values(np.array(m["values"], dtype=np.uint64), 3, True, 2)   # blinding unsupported
+
+
+@pytest.mark.parametrize("ncols,lg,rate,cap", [(1, 3, 3, 4), (3, 0, 3, 2), (4, 5, 3, 4), (20, 10, 3, 4), (135, 12, 3, 4), (16, 13, 3, 4)])
+def test_polynomial_batch_matches_oracle(gpu, orc, ncols, lg, rate, cap):
+    p, ctx = gpu
+    vals = rand_field(500 + ncols, (ncols, 1 << lg))
+    for from_values in (True, False):
+        ob = orc.batch(vals, rate, cap, from_values=from_values, threads=8)
+        gb = (p.PolynomialBatch.from_values if from_values else p.PolynomialBatch.from_coeffs)(vals, rate, False, cap)
+        assert (gb.polynomials == ob.polynomials).all()
+        assert (gb.cap == ob.cap).all()
+        N = 1 << (lg + rate)
+        lde = gb.lde_values()
+        for j in sorted({0, 1, N // 3, N - 1}):
+            leaf = gb.get_leaf(j)
+            assert (leaf == ob.get_leaf(j)).all()
+            sib = gb.prove(j)
+            assert (sib == ob.prove(j)).all()
+            assert orc.merkle_verify(leaf, j, gb.cap, sib)
+            rev = int(format(j, "0%db" % (lg + rate))[::-1], 2) if lg + rate else 0
+            assert (lde[:, rev] == leaf).all()
+            assert (gb.get_lde_values(rev, 1) == leaf).all()      # oracle.rs:128-133
+        gb.free()

@@ -1,0 +1,142 @@
+"""CPU tests: the oracle (oracle/*.hpp) against the reference's known answers and an independent Python model.
+
+These pin the CPU restatement before it is trusted as the checker of the HIP path."""
+import numpy as np
+
+from oracle_lib import P, rand_field, splitmix64
+
+
+def ints(a):
+    return [int(x) for x in np.asarray(a).reshape(-1)]
+
+
+def test_field_edge_grid_closed_forms(orc, golden):
+    # field/src/prime_field_testing.rs:78-180: every op on the edge grid equals the u128 % p closed form
+    g = golden["field_grid"]
+    a = np.array([x for x in g for _ in g], dtype=np.uint64)
+    b = np.array([y for _ in g for y in g], dtype=np.uint64)
+    for op, f in ((0, lambda x, y: (x + y) % P), (1, lambda x, y: (x - y) % P), (2, lambda x, y: (x * y) % P)):
+        got = ints(orc.field_op(op, a, b))
+        assert got == [f(int(x), int(y)) for x, y in zip(a, b)]
+    ga = np.array(g, dtype=np.uint64)
+    assert ints(orc.field_op(3, ga)) == [(-int(x)) % P for x in g]
+    assert ints(orc.field_op(5, ga)) == [int(x) % P for x in g]
+    nz = np.array([x for x in g if x % P], dtype=np.uint64)
+    assert ints(orc.field_op(4, nz)) == [pow(int(x), P - 2, P) for x in nz]
+    c = np.roll(a, 7)
+    assert ints(orc.field_op(6, a, b, c)) == [(int(x) + int(y) * int(z)) % P for x, y, z in zip(a, b, c)]
+
+
+def test_extension_field(orc):
+    a = rand_field(1, 64).reshape(-1, 2)
+    b = rand_field(2, 64).reshape(-1, 2)
+    got = orc.ext_op(2, a, b).reshape(-1, 2)
+    for (a0, a1), (b0, b1), (c0, c1) in zip(a.tolist(), b.tolist(), got.tolist()):
+        assert c0 == (a0 * b0 + 7 * a1 * b1) % P and c1 == (a0 * b1 + a1 * b0) % P
+    inv = orc.ext_op(3, a)
+    one = orc.ext_op(2, a, inv).reshape(-1, 2)
+    assert (one[:, 0] == 1).all() and (one[:, 1] == 0).all()
+
+
+def test_roots_of_unity(orc):
+    # field/src/types.rs:268-272, goldilocks_field.rs:87
+    for lg in (1, 2, 6, 20, 32):
+        w = orc.primitive_root(lg)
+        assert pow(w, 1 << lg, P) == 1 and pow(w, 1 << (lg - 1), P) == P - 1
+    assert orc.primitive_root(6) == 1 << 39   # 64th root is a power of two: the HIP butterflies rely on it
+    assert pow(7, (P - 1) >> 32, P) == 1753635133440165772
+
+
+def test_fft_reference_test_case(orc, golden):
+    # field/src/fft.rs:219-253
+    c = np.array(golden["fft256"]["coeffs"], dtype=np.uint64)
+    v = orc.fft(c)
+    assert ints(v) == golden["fft256"]["values"]
+    assert ints(orc.evaluate_naive(c)) == golden["fft256"]["values"]
+    assert (orc.ifft(v) == c).all()
+    for r in range(4):
+        z = np.concatenate([c, np.zeros(256 * ((1 << r) - 1), dtype=np.uint64)])
+        assert (orc.fft(z) == orc.fft(z, zero_factor=r)).all()
+
+
+def test_ntt_python_model(orc, golden):
+    for case in golden["ntt_model"]:
+        c = np.array(case["coeffs"], dtype=np.uint64)
+        assert ints(orc.fft(c)) == case["values"]
+        assert ints(orc.coset_fft(c, 7)) == case["coset7"]
+        assert (orc.coset_ifft(np.array(case["coset7"], dtype=np.uint64), 7) == c).all()
+    m = golden["lde_model"]
+    assert ints(orc.lde(np.array(m["coeffs"], dtype=np.uint64), m["rate_bits"])) == m["values"]
+
+
+def test_bit_reverse_table(golden):
+    # plonky2/src/util/mod.rs:57-77
+    import oracle_lib  # noqa: F401
+    assert golden["bitrev256"] == [int(format(i, "08b")[::-1], 2) for i in range(256)]
+
+
+def test_poseidon_known_answers(orc, golden):
+    # plonky2/src/hash/poseidon_goldilocks.rs:449-485 and poseidon.rs:777-790 (fast == naive)
+    for kat in golden["poseidon_kats"] + golden["poseidon_model"]:
+        s = np.array(kat["input"], dtype=np.uint64)
+        assert ints(orc.poseidon(s)) == kat["output"]
+        assert ints(orc.poseidon(s, naive=True)) == kat["output"]
+    r = rand_field(3, (64, 12))
+    assert (orc.poseidon(r) == orc.poseidon(r, naive=True)).all()
+
+
+def test_sponge_and_noop(orc):
+    # hashing.rs:117-146: overwrite mode, a short last chunk leaves the rest of the rate untouched
+    x = splitmix64(5, 11)
+    st = np.zeros(12, dtype=np.uint64)
+    st[:8] = x[:8]
+    st = orc.poseidon(st)
+    st[:3] = x[8:]
+    st = orc.poseidon(st)
+    assert (orc.hash_no_pad(x) == st[:4]).all()
+    assert (orc.hash_or_noop(x) == st[:4]).all()
+    # config.rs:55-62: <= 4 elements are copied canonically, not hashed
+    short = np.array([P + 5, 3, (1 << 64) - 1], dtype=np.uint64)
+    assert ints(orc.hash_or_noop(short)) == [5, 3, ((1 << 64) - 1) % P, 0]
+    assert ints(orc.hash_no_pad(np.zeros(0, dtype=np.uint64))) == [0, 0, 0, 0]
+
+
+def test_merkle_python_model(orc, golden):
+    m = golden["merkle_model"]
+    leaves = np.array(m["leaves"], dtype=np.uint64)
+    for t in m["trees"]:
+        tree = orc.merkle(leaves, t["cap_height"])
+        assert tree.cap.tolist() == t["cap"]
+        for idx, sib in t["paths"].items():
+            assert tree.prove(int(idx)).tolist() == sib
+    s = golden["merkle_short"]
+    assert orc.merkle(np.array(s["leaves"], dtype=np.uint64), s["cap_height"]).cap.tolist() == s["cap"]
+
+
+def test_merkle_every_leaf_verifies(orc):
+    # plonky2/src/hash/merkle_tree.rs:223-281: n = 256 leaves x 7, cap heights 1 and 8 (+0, 4)
+    leaves = rand_field(9, (256, 7))
+    for cap_height in (0, 1, 4, 8):
+        tree = orc.merkle(leaves, cap_height)
+        cap = tree.cap
+        for i in range(256):
+            assert orc.merkle_verify(leaves[i], i, cap, tree.prove(i))
+        bad = leaves[3].copy()
+        bad[0] ^= 1
+        assert not orc.merkle_verify(bad, 3, cap, tree.prove(3))
+
+
+def test_polynomial_batch_python_model(orc, golden):
+    m = golden["batch_model"]
+    b = orc.batch(np.array(m["values"], dtype=np.uint64), m["rate_bits"], m["cap_height"], from_values=True)
+    assert b.polynomials.tolist() == m["coeffs"]
+    assert b.cap.tolist() == m["cap"]
+    assert b.get_leaf(13).tolist() == m["leaf_13"]
+    lde = np.array(m["lde"], dtype=np.uint64)           # [ncols][N] natural order
+    leaves = b.leaves()
+    for j in range(64):
+        assert leaves[j].tolist() == lde[:, int(format(j, "06b")[::-1], 2)].tolist()   # oracle.rs:83-84
+    m9 = golden["batch_model9"]
+    b9 = orc.batch(np.array(m9["values"], dtype=np.uint64), m9["rate_bits"], m9["cap_height"], from_values=True, threads=2)
+    assert b9.cap.tolist() == m9["cap"]
+    assert b9.prove(37).tolist() == m9["path_37"]

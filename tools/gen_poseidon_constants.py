@@ -168,25 +168,21 @@ KATS = [
 
 
 def emit(path, rc, T):
+    """Writes <path> (host wrapper, guarded) and <path minus .h>.inc (raw tables behind POSEIDON_TABLE)."""
     def arr(name, vals, per_line=4):
-        out = ["static const uint64_t %s[%d] = {" % (name, len(vals))]
+        out = ["POSEIDON_TABLE(%s, %d) = {" % (name, len(vals))]
         for i in range(0, len(vals), per_line):
             out.append("    " + ", ".join("0x%016xULL" % v for v in vals[i:i + per_line]) + ",")
         out.append("};")
         return "\n".join(out)
 
     flat = lambda rows: [x for row in rows for x in row]
-    txt = [
+    inc = [
         "// GENERATED by tools/gen_poseidon_constants.py -- do not edit.",
         "// Poseidon over Goldilocks, width 12, rate 8, x^7, 4+22+4 rounds.",
         "// Round constants are data (tools/poseidon_round_constants.txt); the partial-round tables are",
         "// derived by the generator and validated against the reference's known-answer vectors.",
-        "#pragma once",
-        "#include <stdint.h>",
-        "#define POSEIDON_WIDTH 12",
-        "#define POSEIDON_RATE 8",
-        "#define POSEIDON_HALF_FULL_ROUNDS 4",
-        "#define POSEIDON_PARTIAL_ROUNDS 22",
+        "// No include guard: the includer defines POSEIDON_TABLE(name, n) (host and device copies).",
         arr("POSEIDON_RC", flat(rc)),
         arr("POSEIDON_MDS_CIRC", MDS_CIRC, 12),
         arr("POSEIDON_MDS_DIAG", MDS_DIAG, 12),
@@ -202,8 +198,24 @@ def emit(path, rc, T):
         arr("POSEIDON_PARTIAL_COL", flat(T["cols_w"])),
         "",
     ]
+    inc_path = path[:-2] + ".inc" if path.endswith(".h") else path + ".inc"
+    with open(inc_path, "w") as f:
+        f.write("\n".join(inc))
+    hdr = [
+        "// GENERATED by tools/gen_poseidon_constants.py -- do not edit.",
+        "#pragma once",
+        "#include <stdint.h>",
+        "#define POSEIDON_WIDTH 12",
+        "#define POSEIDON_RATE 8",
+        "#define POSEIDON_HALF_FULL_ROUNDS 4",
+        "#define POSEIDON_PARTIAL_ROUNDS 22",
+        "#define POSEIDON_TABLE(name, n) static const uint64_t name[n]",
+        '#include "%s"' % os.path.basename(inc_path),
+        "#undef POSEIDON_TABLE",
+        "",
+    ]
     with open(path, "w") as f:
-        f.write("\n".join(txt))
+        f.write("\n".join(hdr))
 
 
 def main():
