@@ -53,6 +53,12 @@ int gl_ctx_synchronize(gl_ctx* ctx);
 /* scratch used between the two NTT passes (elements); default 2^24 (128 MiB). */
 int gl_ctx_set_scratch_elems(gl_ctx* ctx, size_t elems);
 const char* gl_last_error(void);
+/* Per-scope device timings (HIP events on the context's stream), the analogue of the reference's TimingTree
+ * (plonky2/src/util/timing.rs:8-192; scopes as in fri/oracle.rs:51-89, plonk/prover.rs:118-316).
+ * Off by default; gl_ctx_timing_report synchronises and writes a JSON object into buf. */
+int gl_ctx_timing_enable(gl_ctx* ctx, int on);
+int gl_ctx_timing_reset(gl_ctx* ctx);
+int gl_ctx_timing_report(gl_ctx* ctx, char* buf, size_t cap);
 /* device memory helpers so that a host language needs no HIP binding of its own */
 int gl_dev_alloc(gl_ctx* ctx, size_t bytes, void** d_out);
 int gl_dev_free(gl_ctx* ctx, void* d_ptr);

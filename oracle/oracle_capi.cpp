@@ -60,6 +60,17 @@ void orc_ifft(u64* data, size_t n, size_t batch) {
         memcpy(data + b * n, v.data(), n * 8);
     }
 }
+// forward (inverse = 0) or inverse transforms of `batch` polynomials, parallel over polynomials like the
+// reference's par_iter over columns (plonky2/src/fri/oracle.rs:54,111-118); each FFT is single-threaded.
+void orc_fft_mt(u64* data, size_t n, size_t batch, int inverse, unsigned threads) {
+    RootTable rt = fft_root_table(n);
+    parallel_for(batch, threads, [&](size_t b) {
+        std::vector<u64> v(data + b * n, data + (b + 1) * n);
+        if (inverse) ifft_inplace(v, &rt); else fft_inplace(v, 0, &rt);
+        canon_all(v);
+        memcpy(data + b * n, v.data(), n * 8);
+    });
+}
 void orc_coset_fft(u64* data, size_t n, size_t batch, u64 shift, unsigned zero_factor) {
     RootTable rt = fft_root_table(n);
     for (size_t b = 0; b < batch; b++) {

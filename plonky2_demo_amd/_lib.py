@@ -44,6 +44,9 @@ SIGNATURES = {
     "gl_ctx_synchronize": (c_int, [c_vp]),
     "gl_ctx_set_scratch_elems": (c_int, [c_vp, c_sz]),
     "gl_last_error": (ctypes.c_char_p, []),
+    "gl_ctx_timing_enable": (c_int, [c_vp, c_int]),
+    "gl_ctx_timing_reset": (c_int, [c_vp]),
+    "gl_ctx_timing_report": (c_int, [c_vp, ctypes.c_char_p, c_sz]),
     "gl_dev_alloc": (c_int, [c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "gl_dev_free": (c_int, [c_vp, c_vp]),
     "gl_copy_h2d": (c_int, [c_vp, c_vp, c_vp, c_sz]),

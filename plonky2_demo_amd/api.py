@@ -81,6 +81,16 @@ class Context:
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 
+    def timing(self, on=True):
+        check(lib.gl_ctx_timing_reset(self.handle))
+        check(lib.gl_ctx_timing_enable(self.handle, 1 if on else 0))
+
+    def timing_report(self):
+        import json
+        buf = ctypes.create_string_buffer(1 << 16)
+        check(lib.gl_ctx_timing_report(self.handle, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
     def close(self):
         if self.handle:
             lib.gl_ctx_destroy(self.handle)

@@ -59,6 +59,14 @@ struct gl_ctx {
     gl_t* dev_small = nullptr;                                    // 1 MiB device staging
     size_t dev_small_bytes = 0;
 
+    // optional per-launch timing (HIP events on the ctx stream); scope names follow the reference's
+    // TimingTree labels where one exists (plonky2/src/util/timing.rs, fri/oracle.rs:51-89)
+    struct TimingRec { const char* name; hipEvent_t start, stop; };
+    bool timing_enabled = false;
+    std::vector<TimingRec> timing_recs;
+    void timing_begin(const char* name);
+    void timing_end();
+
     int activate();
     int ensure_scratch(size_t elems);
     int ensure_pinned(size_t bytes);

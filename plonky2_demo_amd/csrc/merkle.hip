@@ -107,13 +107,17 @@ int gl_merkle_build(gl_ctx* c, const gl_t* base, const uint64_t* host_offsets, u
     const uint64_t* d_off = nullptr;
     GL_TRY(c->get_offsets_table(host_offsets, leaf_len, &d_off));
     const uint32_t n = 1u << lg_leaves;
+    c->timing_begin("merkle_leaf_hash");
     hipLaunchKernelGGL(k_merkle_leaves, dim3((n + 255) / 256), dim3(256), 0, c->stream, base, d_off, leaf_len, lg_leaves, out->level_ptr(0));
+    c->timing_end();
     GL_CHECK_HIP(hipGetLastError());
+    c->timing_begin("merkle_levels");
     for (uint32_t l = 1; l < levels; l++) {
         const uint32_t cnt = 1u << (lg_leaves - l);
         hipLaunchKernelGGL(k_merkle_level, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, out->level_ptr(l - 1), out->level_ptr(l), cnt);
-        GL_CHECK_HIP(hipGetLastError());
     }
+    c->timing_end();
+    GL_CHECK_HIP(hipGetLastError());
     return GL_OK;
 }
 void gl_merkle_release(GlMerkle* m) {

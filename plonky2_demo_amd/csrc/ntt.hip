@@ -62,6 +62,63 @@ int gl_ctx::get_pow_table(gl_t base, gl_t scale, uint32_t hi_len, GlPowTable* ou
     return GL_OK;
 }
 
+void gl_ctx::timing_begin(const char* name) {
+    if (!timing_enabled) return;
+    TimingRec r; r.name = name;
+    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+    (void)hipEventRecord(r.start, stream);
+    timing_recs.push_back(r);
+}
+void gl_ctx::timing_end() {
+    if (!timing_enabled || timing_recs.empty()) return;
+    (void)hipEventRecord(timing_recs.back().stop, stream);
+}
+struct GlTimed {
+    gl_ctx* c;
+    GlTimed(gl_ctx* ctx, const char* name) : c(ctx) { c->timing_begin(name); }
+    ~GlTimed() { c->timing_end(); }
+};
+
+extern "C" int gl_ctx_timing_enable(gl_ctx* c, int on) {
+    GL_REQUIRE(c, GL_ERR_ARG, "null ctx");
+    c->timing_enabled = on != 0;
+    return GL_OK;
+}
+extern "C" int gl_ctx_timing_reset(gl_ctx* c) {
+    GL_REQUIRE(c, GL_ERR_ARG, "null ctx");
+    GL_TRY(c->activate());
+    GL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    for (auto& r : c->timing_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    c->timing_recs.clear();
+    return GL_OK;
+}
+// writes a JSON object {"scope": {"count": n, "ms": total}, ...} into buf (NUL-terminated)
+extern "C" int gl_ctx_timing_report(gl_ctx* c, char* buf, size_t cap) {
+    GL_REQUIRE(c && buf && cap > 2, GL_ERR_ARG, "bad argument");
+    GL_TRY(c->activate());
+    GL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    std::map<std::string, std::pair<uint64_t, double>> agg;
+    std::vector<std::string> order;
+    for (auto& r : c->timing_recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) continue;
+        if (!agg.count(r.name)) order.push_back(r.name);
+        auto& a = agg[r.name];
+        a.first++; a.second += ms;
+    }
+    std::string out = "{";
+    for (size_t i = 0; i < order.size(); i++) {
+        char line[256];
+        snprintf(line, sizeof line, "%s\"%s\": {\"count\": %llu, \"ms\": %.6f}", i ? ", " : "", order[i].c_str(),
+                 (unsigned long long)agg[order[i]].first, agg[order[i]].second);
+        out += line;
+    }
+    out += "}";
+    GL_REQUIRE(out.size() + 1 <= cap, GL_ERR_ARG, "timing report buffer too small");
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return GL_OK;
+}
+
 int gl_ctx::get_offsets_table(const uint64_t* host, size_t len, const uint64_t** d_out) {
     std::vector<uint64_t> key(host, host + len);
     auto it = offset_tables.find(key);
@@ -160,6 +217,7 @@ static int launch_col(gl_ctx* c, const NttPassParams& p, dim3 grid) {
         GL_CHECK_HIP(hipFuncSetAttribute((const void*)ntt_col_pass<LOGL, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    GlTimed timed(c, INV ? "ntt_col_pass(inverse)" : "ntt_col_pass(forward)");
     hipLaunchKernelGGL((ntt_col_pass<LOGL, INV>), grid, dim3(NTT_THREADS), lds, c->stream, p);
     GL_CHECK_HIP(hipGetLastError());
     return GL_OK;
@@ -173,6 +231,7 @@ static int launch_row(gl_ctx* c, const NttPassParams& p, dim3 grid) {
         GL_CHECK_HIP(hipFuncSetAttribute((const void*)ntt_row_pass<LOGL, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    GlTimed timed(c, INV ? "ntt_row_pass(inverse)" : "ntt_row_pass(forward)");
     hipLaunchKernelGGL((ntt_row_pass<LOGL, INV>), grid, dim3(NTT_THREADS), lds, c->stream, p);
     GL_CHECK_HIP(hipGetLastError());
     return GL_OK;
