@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="polynomials of 2^20 per GPU (64 -> 512 MiB, beyond the 256 MiB Infinity Cache)")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--scratch-log", type=int, default=0, help="log2 of the inter-pass scratch in elements (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -94,6 +95,8 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = Context(device=local_rank, stream=stream)
+    if args.scratch_log:
+        ctx.set_scratch_elems(1 << args.scratch_log)
     B, L = args.batch, 1 << LOG_N
     data = synth_field(torch, (B, L), 20 + rank, dev)
     ref = data.clone()

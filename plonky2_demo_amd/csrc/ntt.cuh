@@ -17,9 +17,14 @@
 #include "gl64.cuh"
 
 #define NTT_TILE_LOG 13                 // elements per workgroup tile (8192 * 8 B = 64 KiB of LDS)
-#define NTT_THREADS 256
+#define NTT_THREADS 512
 #define NTT_EPT ((1 << NTT_TILE_LOG) / NTT_THREADS)   // 32 elements per thread
 #define NTT_LOCAL_MAX_LOG 12            // largest in-LDS transform
+#ifdef NTT_ABLATION
+#define NTT_DBG(p, bit) ((p).debug & (bit))
+#else
+#define NTT_DBG(p, bit) 0
+#endif
 #define NTT_SPLIT_LOG 11                // two-level power tables: x^e = lo[e & 2047] * hi[e >> 11]
 
 struct NttPassParams {
@@ -34,6 +39,9 @@ struct NttPassParams {
     const gl_t* pre_lo; const gl_t* pre_hi;    // optional input scale by s^i (two-level), or null
     const gl_t* post_lo; const gl_t* post_hi;  // optional output scale by c*s^k (two-level), or null
     gl_t post_const;                   // scalar output factor when post tables are null (1 = none)
+#ifdef NTT_ABLATION
+    uint32_t debug;                    // diagnostic builds only (-DNTT_ABLATION, env GL_NTT_DEBUG): 1 skip stages, 2 skip loads, 4 skip stores
+#endif
 };
 
 __host__ __device__ constexpr int ntt_first_radix(int rem) {
@@ -73,30 +81,65 @@ __device__ __forceinline__ gl_t ntt_pow2level(const gl_t* lo, const gl_t* hi, ui
     return gl_mul(lo[e & ((1u << NTT_SPLIT_LOG) - 1)], hi[e >> NTT_SPLIT_LOG]);
 }
 
-// One Stockham stage over the tile in LDS: L = 2^LOGL points per column, T = 2^LOGT columns,
-// Ns = 2^LOGNS points already combined.  Layout: lds[i * LDT + t].
-template <int LOGL, int LOGT, int LOGNS, bool INV>
+// ---- LDS tile layout --------------------------------------------------------------------------------
+// LOGL <= 10 ("wave-owned"): the tile holds T columns of L points, column-major: lds[t * LW + phi(i)].
+// One wave (64 lanes x 16 elements) owns 1024/L whole columns, so all radix stages of a column are
+// wave-local: they need no workgroup barrier, only program order (LDS executes a wave's accesses in
+// order) and a compiler-level wave barrier.  phi() XORs the low four index bits with the next four so that
+// the stride-16 writes of the first radix-16 stage hit 16 different banks.
+// LOGL > 10: columns span several waves: layout lds[i * (T+1) + t] with workgroup barriers per stage.
+template <int LOGL>
+struct NttGeom {
+    static constexpr int LOGT = NTT_TILE_LOG - LOGL, T = 1 << LOGT, L = 1 << LOGL;
+    static constexpr bool WAVE_OWNED = (LOGL <= 10);
+    static constexpr int LW = L + (LOGL >= 4 ? (T == 8 ? 2 : 1) : 0);         // column stride (elements)
+    static constexpr int LDT = T + 1;                                          // row stride of the legacy layout
+    static constexpr size_t LDS_BYTES = WAVE_OWNED ? (size_t)T * LW * 8 : (size_t)L * LDT * 8;
+    __device__ static __forceinline__ int at(int t, int i) {
+        if constexpr (WAVE_OWNED) return t * LW + (i ^ ((i >> 4) & 15));
+        else return i * LDT + t;
+    }
+};
+
+__device__ __forceinline__ void ntt_wave_sync() {
+    // orders this wave's LDS accesses (hardware keeps them in issue order); stops compiler reordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// All Stockham stages over the tile in LDS: L = 2^LOGL points per column, Ns = 2^LOGNS already combined.
+template <int LOGL, int LOGNS, bool INV>
 __device__ __forceinline__ void ntt_lds_stages(gl_t* lds, const gl_t* __restrict__ tw_local, int tid) {
     if constexpr (LOGNS < LOGL) {
+        using G = NttGeom<LOGL>;
         constexpr int LOGR = ntt_first_radix(LOGL - LOGNS);
         constexpr int R = 1 << LOGR;
-        constexpr int T = 1 << LOGT, LDT = T + 1;
         constexpr int TPT = NTT_EPT / R;                 // tasks per thread
         constexpr int LOGJ = LOGL - LOGR;                // tasks per column = 2^LOGJ
         constexpr int NS = 1 << LOGNS;
         gl_t u[TPT][R];
+        int tcol[TPT], tj[TPT];
 #pragma unroll
         for (int q = 0; q < TPT; q++) {
-            const int task = tid + NTT_THREADS * q;
-            const int t = task & (T - 1), j = task >> LOGT;
+            if constexpr (G::WAVE_OWNED) {
+                constexpr int CPW = G::T / (NTT_THREADS / 64);       // columns per wave
+                const int wave = tid >> 6, lane = tid & 63;
+                const int w_task = lane + 64 * q;                    // < 1024 / R
+                tcol[q] = wave * CPW + (w_task >> LOGJ);
+                tj[q] = w_task & ((1 << LOGJ) - 1);
+            } else {
+                const int task = tid + NTT_THREADS * q;
+                tcol[q] = task & (G::T - 1);
+                tj[q] = task >> G::LOGT;
+            }
 #pragma unroll
-            for (int r = 0; r < R; r++) u[q][r] = lds[(j + (r << LOGJ)) * LDT + t];
+            for (int r = 0; r < R; r++) u[q][r] = lds[G::at(tcol[q], tj[q] + (r << LOGJ))];
         }
-        __syncthreads();
+        if constexpr (G::WAVE_OWNED) ntt_wave_sync(); else __syncthreads();
 #pragma unroll
         for (int q = 0; q < TPT; q++) {
-            const int task = tid + NTT_THREADS * q;
-            const int t = task & (T - 1), j = task >> LOGT;
+            const int j = tj[q];
             const int k = j & (NS - 1);
             if constexpr (LOGNS > 0) {
 #pragma unroll
@@ -106,51 +149,60 @@ __device__ __forceinline__ void ntt_lds_stages(gl_t* lds, const gl_t* __restrict
             ntt_small_dft<LOGR, INV>(u[q]);
             const int j0 = ((j - k) << LOGR) + k;
 #pragma unroll
-            for (int o = 0; o < R; o++) lds[(j0 + (o << LOGNS)) * LDT + t] = u[q][ntt_bitrev(o, LOGR)];
+            for (int o = 0; o < R; o++) lds[G::at(tcol[q], j0 + (o << LOGNS))] = u[q][ntt_bitrev(o, LOGR)];
         }
-        __syncthreads();
-        ntt_lds_stages<LOGL, LOGT, LOGNS + LOGR, INV>(lds, tw_local, tid);
+        if constexpr (G::WAVE_OWNED) ntt_wave_sync(); else __syncthreads();
+        ntt_lds_stages<LOGL, LOGNS + LOGR, INV>(lds, tw_local, tid);
     }
 }
 
 // COLUMN pass (pass A).  grid = (N2 / T, batch).
 template <int LOGL, bool INV>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_col_pass(NttPassParams p) {
-    constexpr int LOGT = NTT_TILE_LOG - LOGL, T = 1 << LOGT, LDT = T + 1, L = 1 << LOGL;
+    using G = NttGeom<LOGL>;
+    constexpr int LOGT = G::LOGT, T = G::T;
     extern __shared__ __align__(16) gl_t lds[];
     const int tid = threadIdx.x;
-    const uint32_t c0 = blockIdx.x << LOGT;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so give
+    // XCD x a contiguous run of column tiles: neighbouring tiles share 128-byte lines when T*8 < 128.
+    uint32_t tile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t c0 = tile << LOGT;
     const uint32_t b = blockIdx.y;
     const uint32_t lgN2 = p.lgN2;
     const gl_t* src = p.src + (uint64_t)b * p.src_stride;
     gl_t* dst = p.dst + (uint64_t)b * p.dst_stride;
     // load: e -> (i1 = e / T, t = e % T), zero beyond n_in
-#pragma unroll 8
+    gl_t v[NTT_EPT];
+#pragma unroll
     for (int q = 0; q < NTT_EPT; q++) {
         const int e = tid + NTT_THREADS * q;
         const uint32_t t = e & (T - 1), i1 = e >> LOGT;
         const uint32_t i = (i1 << lgN2) + c0 + t;
-        gl_t v = 0;
-        if (i < p.n_in) {
-            v = src[i];
-            if (p.pre_lo) v = gl_mul(v, ntt_pow2level(p.pre_lo, p.pre_hi, i));
-        }
-        lds[i1 * LDT + t] = v;
+        v[q] = (i < p.n_in && !NTT_DBG(p, 2)) ? src[i] : (gl_t)e;
+    }
+#pragma unroll
+    for (int q = 0; q < NTT_EPT; q++) {
+        const int e = tid + NTT_THREADS * q;
+        const uint32_t t = e & (T - 1), i1 = e >> LOGT;
+        const uint32_t i = (i1 << lgN2) + c0 + t;
+        gl_t x = v[q];
+        if (p.pre_lo && i < p.n_in) x = gl_mul(x, ntt_pow2level(p.pre_lo, p.pre_hi, i));
+        lds[G::at(t, i1)] = x;
     }
     __syncthreads();
-    ntt_lds_stages<LOGL, LOGT, 0, INV>(lds, p.tw_local, tid);
+    if (!NTT_DBG(p, 1)) ntt_lds_stages<LOGL, 0, INV>(lds, p.tw_local, tid);
+    if constexpr (G::WAVE_OWNED) __syncthreads();
     // store with the inter-pass twiddle w_N^(i2*k1)
 #pragma unroll 4
     for (int q = 0; q < NTT_EPT; q++) {
         const int e = tid + NTT_THREADS * q;
         const uint32_t t = e & (T - 1), k1 = e >> LOGT;
         const uint32_t i2 = c0 + t;
-        gl_t v = lds[k1 * LDT + t];
-        const uint32_t ex = i2 * k1;
-        if (ex) v = gl_mul(v, ntt_pow2level(p.tw_lo, p.tw_hi, ex));
-        dst[((uint64_t)k1 << lgN2) + i2] = v;
+        gl_t x = lds[G::at(t, k1)];
+        x = gl_mul(x, ntt_pow2level(p.tw_lo, p.tw_hi, i2 * k1));
+        if (!NTT_DBG(p, 4) || x == 12345) dst[((uint64_t)k1 << lgN2) + i2] = x;
     }
-    (void)L;
 }
 
 // ROW pass (pass B, or the only pass when lgN1 == 0).
@@ -158,33 +210,41 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_col_pass(NttPassParams p) {
 //   single:     grid = (ceil(batch / T), 1): T polynomials
 template <int LOGL, bool INV>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_row_pass(NttPassParams p) {
-    constexpr int LOGT = NTT_TILE_LOG - LOGL, T = 1 << LOGT, LDT = T + 1, L = 1 << LOGL;
+    using G = NttGeom<LOGL>;
+    constexpr int LOGT = G::LOGT, T = G::T, L = G::L;
     extern __shared__ __align__(16) gl_t lds[];
     const int tid = threadIdx.x;
     const bool single = (p.lgN1 == 0);
-    const uint32_t r0 = blockIdx.x << LOGT;                 // first row (k1) or first polynomial
+    uint32_t tile = blockIdx.x;
+    if (!single && (gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t r0 = tile << LOGT;                       // first row (k1) or first polynomial
     const uint32_t b = single ? 0 : blockIdx.y;
     const gl_t* src = p.src + (uint64_t)b * p.src_stride;
     gl_t* dst = p.dst + (uint64_t)b * p.dst_stride;
     // load: e -> (r = e / L, i2 = e % L): contiguous rows
-#pragma unroll 8
+    gl_t v[NTT_EPT];
+#pragma unroll
     for (int q = 0; q < NTT_EPT; q++) {
         const int e = tid + NTT_THREADS * q;
         const uint32_t i2 = e & (L - 1), r = e >> LOGL;
-        gl_t v = 0;
         if (single) {
             const uint32_t poly = r0 + r;
-            if (poly < p.batch && i2 < p.n_in) {
-                v = p.src[(uint64_t)poly * p.src_stride + i2];
-                if (p.pre_lo) v = gl_mul(v, ntt_pow2level(p.pre_lo, p.pre_hi, i2));
-            }
+            v[q] = (poly < p.batch && i2 < p.n_in) ? p.src[(uint64_t)poly * p.src_stride + i2] : 0;
         } else {
-            v = src[((uint64_t)(r0 + r) << LOGL) + i2];
+            v[q] = NTT_DBG(p, 2) ? (gl_t)e : src[((uint64_t)(r0 + r) << LOGL) + i2];
         }
-        lds[i2 * LDT + r] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < NTT_EPT; q++) {
+        const int e = tid + NTT_THREADS * q;
+        const uint32_t i2 = e & (L - 1), r = e >> LOGL;
+        gl_t x = v[q];
+        if (single && p.pre_lo && i2 < p.n_in) x = gl_mul(x, ntt_pow2level(p.pre_lo, p.pre_hi, i2));
+        lds[G::at(r, i2)] = x;
     }
     __syncthreads();
-    ntt_lds_stages<LOGL, LOGT, 0, INV>(lds, p.tw_local, tid);
+    if (!NTT_DBG(p, 1)) ntt_lds_stages<LOGL, 0, INV>(lds, p.tw_local, tid);
+    if constexpr (G::WAVE_OWNED) __syncthreads();
     if (single) {
         // store rows contiguously: e -> (r = e / L, k = e % L)
 #pragma unroll 4
@@ -193,10 +253,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_row_pass(NttPassParams p) {
             const uint32_t k = e & (L - 1), r = e >> LOGL;
             const uint32_t poly = r0 + r;
             if (poly < p.batch) {
-                gl_t v = lds[k * LDT + r];
-                if (p.post_lo) v = gl_mul(v, ntt_pow2level(p.post_lo, p.post_hi, k));
-                else if (p.post_const != 1) v = gl_mul(v, p.post_const);
-                p.dst[(uint64_t)poly * p.dst_stride + k] = gl_canon(v);
+                gl_t x = lds[G::at(r, k)];
+                if (p.post_lo) x = gl_mul(x, ntt_pow2level(p.post_lo, p.post_hi, k));
+                else if (p.post_const != 1) x = gl_mul(x, p.post_const);
+                p.dst[(uint64_t)poly * p.dst_stride + k] = gl_canon(x);
             }
         }
     } else {
@@ -207,10 +267,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_row_pass(NttPassParams p) {
             const int e = tid + NTT_THREADS * q;
             const uint32_t r = e & (T - 1), k2 = e >> LOGT;
             const uint32_t k = (r0 + r) + (k2 << lgN1);
-            gl_t v = lds[k2 * LDT + r];
-            if (p.post_lo) v = gl_mul(v, ntt_pow2level(p.post_lo, p.post_hi, k));
-            else if (p.post_const != 1) v = gl_mul(v, p.post_const);
-            dst[k] = gl_canon(v);
+            gl_t x = lds[G::at(r, k2)];
+            if (p.post_lo) x = gl_mul(x, ntt_pow2level(p.post_lo, p.post_hi, k));
+            else if (p.post_const != 1) x = gl_mul(x, p.post_const);
+            if (!NTT_DBG(p, 4) || x == 12345) dst[k] = gl_canon(x);
         }
     }
 }

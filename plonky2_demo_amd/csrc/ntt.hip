@@ -3,6 +3,7 @@
 #include "ntt.cuh"
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 thread_local std::string g_gl_last_error;
 
@@ -210,8 +211,7 @@ extern "C" int gl_copy_d2h(gl_ctx* c, void* h_dst, const void* d_src, size_t byt
 // ---------------------------------------------------------------------------------------- launchers
 template <int LOGL, bool INV>
 static int launch_col(gl_ctx* c, const NttPassParams& p, dim3 grid) {
-    constexpr int T = 1 << (NTT_TILE_LOG - LOGL);
-    constexpr size_t lds = (size_t)(1 << LOGL) * (T + 1) * sizeof(gl_t);
+    constexpr size_t lds = NttGeom<LOGL>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         GL_CHECK_HIP(hipFuncSetAttribute((const void*)ntt_col_pass<LOGL, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -224,8 +224,7 @@ static int launch_col(gl_ctx* c, const NttPassParams& p, dim3 grid) {
 }
 template <int LOGL, bool INV>
 static int launch_row(gl_ctx* c, const NttPassParams& p, dim3 grid) {
-    constexpr int T = 1 << (NTT_TILE_LOG - LOGL);
-    constexpr size_t lds = (size_t)(1 << LOGL) * (T + 1) * sizeof(gl_t);
+    constexpr size_t lds = NttGeom<LOGL>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         GL_CHECK_HIP(hipFuncSetAttribute((const void*)ntt_row_pass<LOGL, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -279,6 +278,9 @@ int gl_ntt_run(gl_ctx* c, const gl_t* src, uint64_t src_stride, uint32_t n_in, g
     memset(&p, 0, sizeof p);
     p.tw_local = c->tw_local[inverse ? 1 : 0];
     p.post_const = 1;
+#ifdef NTT_ABLATION
+    { const char* dbg = getenv("GL_NTT_DEBUG"); p.debug = dbg ? (uint32_t)atoi(dbg) : 0; }
+#endif
     GlPowTable pre, post, tw;
     if (pre_shift) GL_TRY(c->get_pow_table(gl_canon(pre_shift), 1, (n_in + (1u << NTT_SPLIT_LOG) - 1) >> NTT_SPLIT_LOG, &pre));
     if (post_shift) GL_TRY(c->get_pow_table(gl_canon(post_shift), gl_canon(post_const), (uint32_t)((N + (1u << NTT_SPLIT_LOG) - 1) >> NTT_SPLIT_LOG), &post));
