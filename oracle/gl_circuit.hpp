@@ -1,0 +1,400 @@
+// ORACLE (test infrastructure only).  CPU restatement of circuit construction + witness generation for the
+// matrix-multiplication demo circuit C = A*B over Goldilocks.
+// Follows:
+//   plonky2/src/bin/matrix_mul.rs:25-81, plonky2/examples/matrix_multiplication.rs:21-67 (the circuit)
+//   plonky2/src/gadgets/arithmetic.rs:34-159,187-213      (arithmetic(), special cases, add, mul)
+//   plonky2/src/plonk/circuit_builder.rs:353-388,424-436,485-496,665-695 (add_gate, connect, constant, find_slot)
+//   plonky2/src/plonk/circuit_builder.rs:913-1146         (build(): PI hashing, PublicInputGate, ConstantGate,
+//                                                         padding, selectors, sigmas, commitment, digest)
+//   plonky2/src/hash/hashing.rs:31-59, hash/poseidon.rs:724-751 (in-circuit sponge, PoseidonGate routing)
+//   plonky2/src/plonk/permutation_argument.rs:21-170      (copy-constraint partition -> sigma)
+//   plonky2/src/gates/selectors.rs:110-185, field/src/cosets.rs:9-24
+//   plonky2/src/iop/witness.rs:340-353, iop/generator.rs:19-98,286-304, gates/poseidon.rs:411-497 (witness)
+//   plonky2/src/plonk/circuit_data.rs:72-90               (standard_recursion_config)
+#pragma once
+#include "gl_batch.hpp"
+#include "gl_gates.hpp"
+#include <algorithm>
+#include <map>
+#include <numeric>
+
+namespace orc {
+
+struct CircuitConfig {                       // circuit_data.rs:72-90
+    size_t num_wires = 135, num_routed_wires = 80, num_constants = 2, num_challenges = 2;
+    size_t max_quotient_degree_factor = 8;
+    unsigned rate_bits = 3, cap_height = 4, proof_of_work_bits = 16, num_query_rounds = 28;
+    unsigned fri_arity_bits = 4, fri_final_poly_bits = 5;      // ConstantArityBits(4, 5)
+};
+
+struct Target {
+    bool is_wire; size_t row, col;           // wire
+    size_t index;                            // virtual
+    static Target wire(size_t r, size_t c) { return Target{true, r, c, 0}; }
+    static Target virt(size_t i) { return Target{false, 0, 0, i}; }
+    bool operator==(const Target& o) const { return is_wire == o.is_wire && row == o.row && col == o.col && index == o.index; }
+};
+
+struct ArithOp { size_t row, slot; u64 c0, c1; };
+
+struct CommonData {
+    CircuitConfig config;
+    unsigned degree_bits = 0;
+    SelectorsInfo selectors;
+    size_t num_gate_constraints = 0, num_constants = 0, num_public_inputs = 0, num_partial_products = 0;
+    size_t quotient_degree_factor = 8;
+    std::vector<u64> k_is;
+    std::vector<unsigned> fri_reduction_arity_bits;
+    size_t degree() const { return size_t(1) << degree_bits; }
+    size_t final_poly_len() const { unsigned t = 0; for (auto a : fri_reduction_arity_bits) t += a; return size_t(1) << (degree_bits - t); }
+};
+
+struct CircuitData {
+    CommonData common;
+    size_t m = 0;
+    // prover-only
+    std::vector<GateType> row_gate;                     // gate type of each row
+    std::vector<std::vector<u64>> constants_sigmas;     // column-major values: 4 constants + 80 sigmas, each n
+    std::vector<u64> subgroup;
+    PolynomialBatch constants_sigmas_commitment;
+    Digest circuit_digest;
+    // witness recipe
+    size_t num_targets = 0;
+    std::vector<size_t> representative;                 // union-find result over all targets (wires then virtual)
+    std::vector<Target> a_targets, b_targets, public_inputs;
+    std::vector<ArithOp> arith_ops;                     // in generator (creation) order
+    std::vector<size_t> poseidon_rows;
+    size_t pi_row = 0, constant_row = 0;
+    std::vector<std::pair<size_t, u64>> constant_wires; // (wire column on constant_row, value)
+    size_t target_index(const Target& t) const {        // iop/target.rs: wires first, then virtual targets
+        return t.is_wire ? t.row * common.config.num_wires + t.col : common.degree() * common.config.num_wires + t.index;
+    }
+};
+
+// ---- the builder -------------------------------------------------------------------------------------
+struct CircuitBuilder {
+    CircuitConfig config;
+    struct GateInstance { GateType type; u64 constants[2]; };
+    std::vector<GateInstance> gate_instances;
+    std::vector<Target> public_inputs;
+    size_t virtual_target_index = 0;
+    std::vector<std::pair<Target, Target>> copy_constraints;
+    std::map<u64, Target> constants_to_targets;                 // keyed by canonical value
+    std::map<size_t, u64> virtual_constants;                    // virtual index -> constant (targets_to_constants)
+    std::map<std::pair<u64, u64>, std::pair<size_t, size_t>> current_slots;   // ArithmeticGate params -> (row, slot)
+    struct ConstGen { size_t row, constant_index, wire_index; };
+    std::vector<ConstGen> constant_generators;
+    std::vector<ArithOp> arith_ops;
+    std::vector<size_t> poseidon_rows;
+
+    Target add_virtual_target() { return Target::virt(virtual_target_index++); }
+    size_t add_gate(GateType t, u64 c0 = 0, u64 c1 = 0) {        // circuit_builder.rs:353-388
+        size_t row = gate_instances.size();
+        if (t == GATE_CONSTANT) for (size_t i = 0; i < config.num_constants; i++) constant_generators.push_back({row, i, i});
+        gate_instances.push_back({t, {c0, c1}});
+        return row;
+    }
+    void connect(Target x, Target y) { copy_constraints.push_back({x, y}); }      // :424-436
+    Target constant(u64 c) {                                                      // :485-496
+        c = canon(c);
+        auto it = constants_to_targets.find(c);
+        if (it != constants_to_targets.end()) return it->second;
+        Target t = add_virtual_target();
+        constants_to_targets[c] = t;
+        virtual_constants[t.index] = c;
+        return t;
+    }
+    Target zero() { return constant(0); }
+    Target one() { return constant(1); }
+    bool target_as_constant(const Target& t, u64* out) const {
+        if (t.is_wire) return false;
+        auto it = virtual_constants.find(t.index);
+        if (it == virtual_constants.end()) return false;
+        *out = it->second; return true;
+    }
+    // gadgets/arithmetic.rs:34-159 (base arithmetic gate path; the memo table cannot hit for this circuit)
+    Target arithmetic(u64 c0, u64 c1, Target m0, Target m1, Target addend) {
+        Target z = zero();
+        u64 v0 = 0, v1 = 0, va = 0;
+        bool k0 = target_as_constant(m0, &v0), k1 = target_as_constant(m1, &v1), ka = target_as_constant(addend, &va);
+        bool first_zero = c0 == 0 || m0 == z || m1 == z;
+        bool second_zero = c1 == 0 || addend == z;
+        bool first_known = first_zero || (k0 && k1), second_known = second_zero || ka;
+        if (first_known && second_known) {
+            u64 x = first_zero ? 0 : mul(mul(v0, v1), c0), y = second_zero ? 0 : mul(va, c1);
+            return constant(add(x, y));
+        }
+        if (first_zero && c1 == 1) return addend;
+        if (second_zero) {
+            if (k0 && canon(mul(v0, c0)) == 1) return m1;
+            if (k1 && canon(mul(v1, c0)) == 1) return m0;
+        }
+        // find_slot(ArithmeticGate, params = constants = [c0, c1])  (circuit_builder.rs:665-695)
+        auto key = std::make_pair(c0, c1);
+        size_t row, slot;
+        auto it = current_slots.find(key);
+        if (it != current_slots.end()) { row = it->second.first; slot = it->second.second; }
+        else { row = add_gate(GATE_ARITHMETIC, c0, c1); slot = 0; }
+        if (slot == 20 - 1) current_slots.erase(key); else current_slots[key] = {row, slot + 1};
+        connect(m0, Target::wire(row, 4 * slot));
+        connect(m1, Target::wire(row, 4 * slot + 1));
+        connect(addend, Target::wire(row, 4 * slot + 2));
+        arith_ops.push_back({row, slot, c0, c1});
+        return Target::wire(row, 4 * slot + 3);
+    }
+    Target mul_t(Target x, Target y) { return arithmetic(1, 0, x, y, x); }                 // arithmetic.rs:210-213
+    Target add_t(Target x, Target y) { Target o = one(); return arithmetic(1, 1, x, o, y); }   // :187-191
+
+    // hash_n_to_hash_no_pad in circuit (hashing.rs:24-59) with PoseidonGate routing (poseidon.rs:724-751)
+    std::array<Target, 4> hash_public_inputs(const std::vector<Target>& inputs) {
+        Target z = zero();
+        std::array<Target, 12> state; state.fill(z);
+        for (size_t off = 0; off < inputs.size(); off += 8) {
+            size_t c = std::min<size_t>(8, inputs.size() - off);
+            for (size_t i = 0; i < c; i++) state[i] = inputs[off + i];
+            Target f = zero();                                  // self._false()
+            size_t row = add_gate(GATE_POSEIDON);
+            poseidon_rows.push_back(row);
+            connect(f, Target::wire(row, PoseidonWires::SWAP));
+            for (int i = 0; i < 12; i++) connect(state[i], Target::wire(row, PoseidonWires::INPUT + i));
+            for (int i = 0; i < 12; i++) state[i] = Target::wire(row, PoseidonWires::OUTPUT + i);
+        }
+        return {state[0], state[1], state[2], state[3]};
+    }
+};
+
+static inline std::vector<unsigned> fri_reduction_arity_bits(const CircuitConfig& c, unsigned degree_bits) {
+    std::vector<unsigned> r;                                     // reduction_strategies.rs:39-49
+    while (degree_bits > c.fri_final_poly_bits && degree_bits + c.rate_bits - c.fri_arity_bits >= c.cap_height) {
+        r.push_back(c.fri_arity_bits); degree_bits -= c.fri_arity_bits;
+    }
+    return r;
+}
+
+// Builds the m x m matmul circuit exactly as the demo does, then runs build().
+static inline CircuitData build_matmul_circuit(size_t m, unsigned threads = 1) {
+    CircuitBuilder b;
+    CircuitData cd;
+    cd.m = m;
+    std::vector<std::vector<Target>> A(m), B(m), C(m);
+    for (size_t i = 0; i < m; i++)
+        for (size_t j = 0; j < m; j++) { A[i].push_back(b.add_virtual_target()); B[i].push_back(b.add_virtual_target()); }
+    for (size_t i = 0; i < m; i++)
+        for (size_t j = 0; j < m; j++) {
+            Target cur = b.constant(0);
+            for (size_t k = 0; k < m; k++) { Target p = b.mul_t(A[i][k], B[k][j]); cur = b.add_t(cur, p); }
+            C[i].push_back(cur);
+        }
+    for (size_t i = 0; i < m; i++)
+        for (size_t j = 0; j < m; j++) { b.public_inputs.push_back(A[i][j]); b.public_inputs.push_back(B[i][j]); b.public_inputs.push_back(C[i][j]); }
+    for (size_t i = 0; i < m; i++) for (size_t j = 0; j < m; j++) { cd.a_targets.push_back(A[i][j]); cd.b_targets.push_back(B[i][j]); }
+
+    // ---- build() (circuit_builder.rs:913-1146) ----
+    const CircuitConfig& cfg = b.config;
+    auto pi_hash = b.hash_public_inputs(b.public_inputs);
+    size_t pi_row = b.add_gate(GATE_PUBLIC_INPUT);
+    for (size_t i = 0; i < 4; i++) b.connect(pi_hash[i], Target::wire(pi_row, i));
+    while (b.constants_to_targets.size() > b.constant_generators.size()) b.add_gate(GATE_CONSTANT);
+    {
+        size_t gi = 0;
+        for (auto& kv : b.constants_to_targets) {               // std::map iterates by canonical value (:946-950)
+            auto g = b.constant_generators[gi++];
+            b.gate_instances[g.row].constants[g.constant_index] = kv.first;
+            b.connect(Target::wire(g.row, g.wire_index), kv.second);
+            cd.constant_row = g.row;
+            cd.constant_wires.push_back({g.wire_index, kv.first});
+        }
+        assert(gi <= 2 && "this restatement places one ConstantGate");
+    }
+    while (b.gate_instances.size() & (b.gate_instances.size() - 1)) b.add_gate(GATE_NOOP);   // blind_and_pad, zk off
+    const size_t degree = b.gate_instances.size();
+    const unsigned degree_bits = log2_strict(degree);
+    CommonData& cm = cd.common;
+    cm.config = cfg; cm.degree_bits = degree_bits;
+    cm.fri_reduction_arity_bits = fri_reduction_arity_bits(cfg, degree_bits);
+    cm.quotient_degree_factor = cfg.max_quotient_degree_factor;
+
+    // gates sorted by (degree, id) (:984-986)
+    std::vector<GateType> gates;
+    for (int g = 0; g < GATE_NUM_TYPES; g++)
+        for (auto& gi : b.gate_instances) if (gi.type == (GateType)g) { gates.push_back((GateType)g); break; }
+    std::sort(gates.begin(), gates.end(), [](GateType x, GateType y) {
+        return std::make_pair(gate_degree(x), gate_id(x)) < std::make_pair(gate_degree(y), gate_id(y)); });
+    // selector_polynomials(gates, instances, max_degree = quotient_degree_factor + 1) (selectors.rs:110-185)
+    SelectorsInfo& si = cm.selectors;
+    si.gates = gates;
+    const size_t max_degree = cm.quotient_degree_factor + 1, num_gates = gates.size();
+    const size_t max_gate_degree = gate_degree(gates.back());
+    if (max_gate_degree + num_gates - 1 <= max_degree) {
+        si.groups.push_back({0, num_gates});
+        si.selector_indices.assign(num_gates, 0);
+    } else {
+        assert(max_gate_degree < max_degree);
+        size_t start = 0;
+        while (start < num_gates) {
+            size_t size = 0;
+            while (start + size < num_gates && size + gate_degree(gates[start + size]) < max_degree) size++;
+            si.groups.push_back({start, start + size});
+            start += size;
+        }
+        for (size_t i = 0; i < num_gates; i++)
+            for (size_t g = 0; g < si.groups.size(); g++) if (i >= si.groups[g].first && i < si.groups[g].second) si.selector_indices.push_back(g);
+    }
+    std::vector<std::vector<u64>> constant_vecs(si.groups.size(), std::vector<u64>(degree));
+    for (size_t j = 0; j < degree; j++) {
+        size_t i = si.gate_index(b.gate_instances[j].type), gr = si.selector_indices[i];
+        for (size_t g = 0; g < si.groups.size(); g++) constant_vecs[g][j] = (si.groups.size() == 1 || g == gr) ? i : UNUSED_SELECTOR;
+    }
+    // constant_polys (:822-843): max_constants over gate types used
+    size_t max_constants = 0;
+    for (auto g : gates) max_constants = std::max<size_t>(max_constants, g == GATE_CONSTANT || g == GATE_ARITHMETIC ? 2 : 0);
+    for (size_t c = 0; c < max_constants; c++) {
+        std::vector<u64> col(degree);
+        for (size_t j = 0; j < degree; j++) col[j] = b.gate_instances[j].constants[c];
+        constant_vecs.push_back(col);
+    }
+    cm.num_constants = constant_vecs.size();
+
+    // subgroup, k_is (cosets.rs:9-24), sigma polynomials (permutation_argument.rs)
+    cd.subgroup.resize(degree);
+    { u64 g = primitive_root_of_unity(degree_bits), x = 1; for (size_t i = 0; i < degree; i++) { cd.subgroup[i] = x; x = mul(x, g); } }
+    { u64 x = 1; for (size_t i = 0; i < cfg.num_routed_wires; i++) { cm.k_is.push_back(x); x = mul(x, GL_GENERATOR); } }
+    cd.num_targets = degree * cfg.num_wires + b.virtual_target_index;
+    std::vector<size_t>& parent = cd.representative;
+    parent.resize(cd.num_targets);
+    std::iota(parent.begin(), parent.end(), size_t(0));
+    auto tindex = [&](const Target& t) { return t.is_wire ? t.row * cfg.num_wires + t.col : degree * cfg.num_wires + t.index; };
+    auto find = [&](size_t x) {
+        size_t r = x; while (parent[r] != r) r = parent[r];
+        while (parent[x] != x) { size_t o = parent[x]; parent[x] = r; x = o; }
+        return r;
+    };
+    for (auto& cc : b.copy_constraints) { size_t x = find(tindex(cc.first)), y = find(tindex(cc.second)); if (x != y) parent[y] = x; }
+    for (size_t i = 0; i < parent.size(); i++) find(i);
+    // neighbours: within a class, routed wires in (row, column) order, cyclic
+    std::vector<size_t> sigma(cfg.num_routed_wires * degree);
+    {
+        std::vector<size_t> first(cd.num_targets, SIZE_MAX), last(cd.num_targets, SIZE_MAX);
+        for (size_t row = 0; row < degree; row++)
+            for (size_t col = 0; col < cfg.num_routed_wires; col++) {
+                size_t rep = parent[row * cfg.num_wires + col];
+                size_t me = col * degree + row;
+                if (first[rep] == SIZE_MAX) first[rep] = me; else sigma[last[rep]] = me;
+                last[rep] = me;
+            }
+        for (size_t rep = 0; rep < cd.num_targets; rep++) if (first[rep] != SIZE_MAX) sigma[last[rep]] = first[rep];
+    }
+    std::vector<std::vector<u64>> sigma_vecs(cfg.num_routed_wires, std::vector<u64>(degree));
+    for (size_t c = 0; c < cfg.num_routed_wires; c++)
+        for (size_t r = 0; r < degree; r++) { size_t x = sigma[c * degree + r]; sigma_vecs[c][r] = mul(cm.k_is[x / degree], cd.subgroup[x % degree]); }
+
+    cd.constants_sigmas = constant_vecs;
+    for (auto& v : sigma_vecs) cd.constants_sigmas.push_back(v);
+    cd.constants_sigmas_commitment = batch_from_values(cd.constants_sigmas, cfg.rate_bits, cfg.cap_height, threads);   // :1020-1028
+
+    cm.num_gate_constraints = 0;
+    for (auto g : gates) cm.num_gate_constraints = std::max(cm.num_gate_constraints, gate_num_constraints(g));
+    cm.num_partial_products = (cfg.num_routed_wires + cm.quotient_degree_factor - 1) / cm.quotient_degree_factor - 1;   // partial_products.rs:40-47
+    cm.num_public_inputs = b.public_inputs.size();
+
+    // circuit digest (:1089-1100): hash_no_pad(cap || hash_pad(domain_separator = []) || [degree_bits])
+    {
+        std::vector<u64> parts;
+        for (auto& d : cd.constants_sigmas_commitment.tree.cap()) for (int k = 0; k < 4; k++) parts.push_back(canon(d.e[k]));
+        std::vector<u64> padded = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};      // config.rs:41-51 pad10*1 of the empty message
+        Digest ds = hash_no_pad(padded.data(), padded.size());
+        for (int k = 0; k < 4; k++) parts.push_back(canon(ds.e[k]));
+        parts.push_back(degree_bits);
+        cd.circuit_digest = hash_no_pad(parts.data(), parts.size());
+    }
+    cd.row_gate.resize(degree);
+    for (size_t j = 0; j < degree; j++) cd.row_gate[j] = b.gate_instances[j].type;
+    cd.public_inputs = b.public_inputs;
+    cd.arith_ops = b.arith_ops;
+    cd.poseidon_rows = b.poseidon_rows;
+    cd.pi_row = pi_row;
+    return cd;
+}
+
+// ---- witness -------------------------------------------------------------------------------------------
+static inline u64 splitmix64_next(u64& x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    u64 z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// PoseidonGenerator (gates/poseidon.rs:430-497): fills delta, s-box-input and output wires of one row
+static inline void poseidon_gate_witness(const u64* in12, u64 swap, u64* row135) {
+    typedef PoseidonWires PW;
+    u64 s[12];
+    for (int i = 0; i < 12; i++) { s[i] = in12[i]; row135[PW::INPUT + i] = in12[i]; }
+    row135[PW::SWAP] = swap;
+    for (int i = 0; i < 4; i++) row135[PW::DELTA + i] = mul(swap, sub(s[i + 4], s[i]));
+    if (canon(swap) == 1) for (int i = 0; i < 4; i++) std::swap(s[i], s[i + 4]);
+    int round = 0;
+    for (int r = 0; r < 4; r++) {
+        pk_constant_layer<u64>(s, round);
+        if (r != 0) for (int i = 0; i < 12; i++) row135[PW::full_sbox_0(r, i)] = s[i];
+        for (int i = 0; i < 12; i++) s[i] = sbox7(s[i]);
+        pk_mds_layer<u64>(s);
+        round++;
+    }
+    pk_partial_init<u64>(s);
+    for (int r = 0; r < POSEIDON_PARTIAL_ROUNDS; r++) {
+        row135[PW::partial_sbox(r)] = s[0];
+        s[0] = add(sbox7(s[0]), POSEIDON_PARTIAL_RC[r]);
+        pk_partial_fast<u64>(s, r);
+    }
+    round += POSEIDON_PARTIAL_ROUNDS;
+    for (int r = 0; r < 4; r++) {
+        pk_constant_layer<u64>(s, round);
+        for (int i = 0; i < 12; i++) row135[PW::full_sbox_1(r, i)] = s[i];
+        for (int i = 0; i < 12; i++) s[i] = sbox7(s[i]);
+        pk_mds_layer<u64>(s);
+        round++;
+    }
+    for (int i = 0; i < 12; i++) row135[PW::OUTPUT + i] = s[i];
+}
+
+struct Witness {
+    std::vector<std::vector<u64>> wire_values;    // [135][n], canonical (iop/witness.rs:256-258)
+    std::vector<u64> public_inputs;
+};
+
+// a, b: row-major m x m inputs.  `filler_seed` drives the 131 values the reference draws from OsRng for the
+// unused PublicInputGate wires (circuit_builder.rs:904-910): the witness MATRIX is the parity boundary.
+static inline Witness generate_witness(const CircuitData& cd, const std::vector<u64>& a, const std::vector<u64>& b, u64 filler_seed) {
+    const size_t nw = cd.common.config.num_wires, degree = cd.common.degree();
+    std::vector<u64> val(cd.num_targets, 0);
+    std::vector<char> set(cd.num_targets, 0);
+    auto rep = [&](const Target& t) { return cd.representative[cd.target_index(t)]; };
+    auto put = [&](const Target& t, u64 v) { size_t r = rep(t); assert(!set[r] || canon(val[r]) == canon(v)); val[r] = canon(v); set[r] = 1; };
+    auto get = [&](const Target& t) { size_t r = rep(t); assert(set[r]); return val[r]; };
+    assert(a.size() == cd.m * cd.m && b.size() == cd.m * cd.m);
+    for (size_t i = 0; i < a.size(); i++) { put(cd.a_targets[i], a[i]); put(cd.b_targets[i], b[i]); }
+    for (auto& cw : cd.constant_wires) put(Target::wire(cd.constant_row, cw.first), cw.second);
+    for (auto& op : cd.arith_ops) {                      // ArithmeticBaseGenerator (arithmetic_base.rs:203-218)
+        u64 m0 = get(Target::wire(op.row, 4 * op.slot)), m1 = get(Target::wire(op.row, 4 * op.slot + 1)), ad = get(Target::wire(op.row, 4 * op.slot + 2));
+        put(Target::wire(op.row, 4 * op.slot + 3), add(mul(mul(m0, m1), op.c0), mul(ad, op.c1)));
+    }
+    std::vector<u64> rowbuf(135);
+    for (size_t row : cd.poseidon_rows) {
+        u64 in[12];
+        for (int i = 0; i < 12; i++) in[i] = get(Target::wire(row, PoseidonWires::INPUT + i));
+        u64 swap = get(Target::wire(row, PoseidonWires::SWAP));
+        poseidon_gate_witness(in, swap, rowbuf.data());
+        for (int c = PoseidonWires::DELTA; c < PoseidonWires::END; c++) put(Target::wire(row, c), rowbuf[c]);
+        for (int i = 0; i < 12; i++) put(Target::wire(row, PoseidonWires::OUTPUT + i), rowbuf[PoseidonWires::OUTPUT + i]);
+    }
+    { u64 st = filler_seed; for (size_t c = 4; c < nw; c++) put(Target::wire(cd.pi_row, c), splitmix64_next(st) % GL_P); }
+    Witness w;
+    w.wire_values.assign(nw, std::vector<u64>(degree, 0));
+    for (size_t i = 0; i < degree; i++)
+        for (size_t j = 0; j < nw; j++) { size_t r = cd.representative[i * nw + j]; if (set[r]) w.wire_values[j][i] = val[r]; }
+    for (auto& t : cd.public_inputs) w.public_inputs.push_back(get(t));
+    return w;
+}
+
+}  // namespace orc

@@ -1,0 +1,191 @@
+// ORACLE (test infrastructure only).  CPU restatement of the gate constraint formulas the matmul demo circuit
+// instantiates, generic over the evaluation field K (K = u64 for the prover's base-field LDE points,
+// K = Ext2 for the verifier's point zeta).
+// Follows:
+//   plonky2/src/gates/arithmetic_base.rs:72-92,163-181   (ArithmeticGate, 20 ops per row)
+//   plonky2/src/gates/poseidon.rs:36-96,113-272          (PoseidonGate wire layout + 123 constraints)
+//   plonky2/src/gates/public_input.rs:97-110, constant.rs:59-66, noop.rs
+//   plonky2/src/gates/gate.rs:121-146,277-284            (filter = prod_{i in group, i != row}(i - s) * (UNUSED - s))
+//   plonky2/src/gates/selectors.rs:14,110-185            (selector groups)
+//   plonky2/src/hash/poseidon.rs:200-214,264-274,311-366,429-450,495-503,552-559 (field-generic layers)
+#pragma once
+#include "gl_poseidon.hpp"
+#include <string>
+
+namespace orc {
+
+// ---- field-generic helpers -------------------------------------------------------------------------
+static inline u64 kadd(u64 a, u64 b) { return add(a, b); }
+static inline u64 ksub(u64 a, u64 b) { return sub(a, b); }
+static inline u64 kmul(u64 a, u64 b) { return mul(a, b); }
+static inline u64 kscal(u64 a, u64 s) { return mul(a, s); }
+static inline Ext2 kadd(Ext2 a, Ext2 b) { return eadd(a, b); }
+static inline Ext2 ksub(Ext2 a, Ext2 b) { return esub(a, b); }
+static inline Ext2 kmul(Ext2 a, Ext2 b) { return emul(a, b); }
+static inline Ext2 kscal(Ext2 a, u64 s) { return escalar(a, s); }
+template <class K> static inline K kconst(u64 c);
+template <> inline u64 kconst<u64>(u64 c) { return c; }
+template <> inline Ext2 kconst<Ext2>(u64 c) { return Ext2{c, 0}; }
+template <class K> static inline K ksbox(K x) { K x2 = kmul(x, x), x4 = kmul(x2, x2), x3 = kmul(x, x2); return kmul(x3, x4); }
+
+enum GateType { GATE_NOOP = 0, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON, GATE_NUM_TYPES };
+static const size_t UNUSED_SELECTOR = 0xFFFFFFFFull;     // selectors.rs:14
+
+static inline unsigned gate_degree(GateType g) {
+    switch (g) { case GATE_NOOP: return 0; case GATE_CONSTANT: return 1; case GATE_PUBLIC_INPUT: return 1;
+                 case GATE_ARITHMETIC: return 3; default: return 7; }
+}
+static inline std::string gate_id(GateType g) {           // Gate::id(): the sort key next to the degree
+    switch (g) {
+        case GATE_NOOP: return "NoopGate";
+        case GATE_CONSTANT: return "ConstantGate { num_consts: 2 }";
+        case GATE_PUBLIC_INPUT: return "PublicInputGate";
+        case GATE_ARITHMETIC: return "ArithmeticGate { num_ops: 20 }";
+        default: return "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>";
+    }
+}
+static inline size_t gate_num_constraints(GateType g) {
+    switch (g) { case GATE_NOOP: return 0; case GATE_CONSTANT: return 2; case GATE_PUBLIC_INPUT: return 4;
+                 case GATE_ARITHMETIC: return 20; default: return 123; }   // poseidon.rs:403-409
+}
+
+// PoseidonGate wire layout (gates/poseidon.rs:36-96)
+struct PoseidonWires {
+    static constexpr int INPUT = 0, OUTPUT = 12, SWAP = 24, DELTA = 25, FULL0 = 29, PARTIAL = 29 + 12 * 3,
+                         FULL1 = PARTIAL + 22, END = FULL1 + 12 * 4;   // END = 135
+    static int full_sbox_0(int round, int i) { return FULL0 + 12 * (round - 1) + i; }
+    static int partial_sbox(int round) { return PARTIAL + round; }
+    static int full_sbox_1(int round, int i) { return FULL1 + 12 * round + i; }
+};
+
+// ---- Poseidon layers over K (the *_field variants of hash/poseidon.rs) -----------------------------
+template <class K> static inline void pk_constant_layer(K (&s)[12], int round) {
+    for (int i = 0; i < 12; i++) s[i] = kadd(s[i], kconst<K>(POSEIDON_RC[12 * round + i]));
+}
+template <class K> static inline void pk_mds_layer(K (&s)[12]) {
+    K out[12];
+    for (int r = 0; r < 12; r++) {
+        K acc = kconst<K>(0);
+        for (int i = 0; i < 12; i++) acc = kadd(acc, kscal(s[(i + r) % 12], POSEIDON_MDS_CIRC[i]));
+        acc = kadd(acc, kscal(s[r], POSEIDON_MDS_DIAG[r]));
+        out[r] = acc;
+    }
+    for (int i = 0; i < 12; i++) s[i] = out[i];
+}
+template <class K> static inline void pk_partial_init(K (&s)[12]) {
+    for (int i = 0; i < 12; i++) s[i] = kadd(s[i], kconst<K>(POSEIDON_PARTIAL_FIRST_RC[i]));
+    K t[12]; t[0] = s[0];
+    for (int c = 1; c < 12; c++) {
+        K acc = kconst<K>(0);
+        for (int r = 1; r < 12; r++) acc = kadd(acc, kscal(s[r], POSEIDON_PARTIAL_INIT[(r - 1) * 11 + (c - 1)]));
+        t[c] = acc;
+    }
+    for (int i = 0; i < 12; i++) s[i] = t[i];
+}
+template <class K> static inline void pk_partial_fast(K (&s)[12], int r) {
+    K d = kscal(s[0], POSEIDON_MDS_CIRC[0] + POSEIDON_MDS_DIAG[0]);
+    for (int i = 1; i < 12; i++) d = kadd(d, kscal(s[i], POSEIDON_PARTIAL_ROW[r * 11 + i - 1]));
+    for (int i = 1; i < 12; i++) s[i] = kadd(s[i], kscal(s[0], POSEIDON_PARTIAL_COL[r * 11 + i - 1]));
+    s[0] = d;
+}
+
+// ---- unfiltered constraints ------------------------------------------------------------------------
+// `consts` = the gate's own constants (local_constants after the selector prefix is removed), `w` = 135 wires
+template <class K>
+static inline void eval_arithmetic(const K* consts, const K* w, K* out) {       // arithmetic_base.rs:72-92
+    for (int i = 0; i < 20; i++) {
+        K computed = kadd(kmul(kmul(w[4 * i], w[4 * i + 1]), consts[0]), kmul(w[4 * i + 2], consts[1]));
+        out[i] = ksub(w[4 * i + 3], computed);
+    }
+}
+template <class K>
+static inline void eval_constant(const K* consts, const K* w, K* out) {         // constant.rs:59-66
+    for (int i = 0; i < 2; i++) out[i] = ksub(consts[i], w[i]);
+}
+template <class K>
+static inline void eval_public_input(const u64* pi_hash, const K* w, K* out) {  // public_input.rs:44-49
+    for (int i = 0; i < 4; i++) out[i] = ksub(w[i], kconst<K>(pi_hash[i]));
+}
+template <class K>
+static inline void eval_poseidon(const K* w, K* out) {                          // poseidon.rs:113-191
+    typedef PoseidonWires PW;
+    int c = 0;
+    K swap = w[PW::SWAP];
+    out[c++] = kmul(swap, ksub(swap, kconst<K>(1)));
+    for (int i = 0; i < 4; i++) out[c++] = ksub(kmul(swap, ksub(w[PW::INPUT + i + 4], w[PW::INPUT + i])), w[PW::DELTA + i]);
+    K s[12];
+    for (int i = 0; i < 4; i++) {
+        s[i] = kadd(w[PW::INPUT + i], w[PW::DELTA + i]);
+        s[i + 4] = ksub(w[PW::INPUT + i + 4], w[PW::DELTA + i]);
+    }
+    for (int i = 8; i < 12; i++) s[i] = w[PW::INPUT + i];
+    int round = 0;
+    for (int r = 0; r < 4; r++) {
+        pk_constant_layer(s, round);
+        if (r != 0)
+            for (int i = 0; i < 12; i++) { K in = w[PW::full_sbox_0(r, i)]; out[c++] = ksub(s[i], in); s[i] = in; }
+        for (int i = 0; i < 12; i++) s[i] = ksbox(s[i]);
+        pk_mds_layer(s);
+        round++;
+    }
+    pk_partial_init(s);
+    for (int r = 0; r < POSEIDON_PARTIAL_ROUNDS; r++) {
+        K in = w[PW::partial_sbox(r)];
+        out[c++] = ksub(s[0], in);
+        s[0] = kadd(ksbox(in), kconst<K>(POSEIDON_PARTIAL_RC[r]));   // last constant is 0 (poseidon.rs:186-189)
+        pk_partial_fast(s, r);
+    }
+    round += POSEIDON_PARTIAL_ROUNDS;
+    for (int r = 0; r < 4; r++) {
+        pk_constant_layer(s, round);
+        for (int i = 0; i < 12; i++) { K in = w[PW::full_sbox_1(r, i)]; out[c++] = ksub(s[i], in); s[i] = in; }
+        for (int i = 0; i < 12; i++) s[i] = ksbox(s[i]);
+        pk_mds_layer(s);
+        round++;
+    }
+    for (int i = 0; i < 12; i++) out[c++] = ksub(s[i], w[PW::OUTPUT + i]);
+    assert(c == 123);
+}
+
+// Selector bookkeeping (selectors.rs:110-185)
+struct SelectorsInfo {
+    std::vector<GateType> gates;                 // sorted by (degree, id): circuit_builder.rs:984-986
+    std::vector<size_t> selector_indices;        // per gate: which selector polynomial
+    std::vector<std::pair<size_t, size_t>> groups;   // [start, end) ranges of gate indices
+    size_t num_selectors() const { return groups.size(); }
+    size_t gate_index(GateType g) const { for (size_t i = 0; i < gates.size(); i++) if (gates[i] == g) return i; assert(false); return 0; }
+};
+
+template <class K>
+static inline K compute_filter(size_t row, std::pair<size_t, size_t> group, K s, bool many) {   // gate.rs:277-284
+    K f = kconst<K>(1);
+    for (size_t i = group.first; i < group.second; i++)
+        if (i != row) f = kmul(f, ksub(kconst<K>(i), s));
+    if (many) f = kmul(f, ksub(kconst<K>(UNUSED_SELECTOR), s));
+    return f;
+}
+
+// Sum of all gates' filtered constraints, slot-wise (vanishing_poly.rs:671-699 / 706-732)
+template <class K>
+static inline void evaluate_gate_constraints(const SelectorsInfo& si, size_t num_gate_constraints,
+                                             const K* local_constants, const K* wires, const u64* pi_hash, K* out) {
+    for (size_t i = 0; i < num_gate_constraints; i++) out[i] = kconst<K>(0);
+    const size_t nsel = si.num_selectors();
+    const K* gc = local_constants + nsel;          // vars.remove_prefix(num_selectors), no lookup selectors here
+    K tmp[123];
+    for (size_t gi = 0; gi < si.gates.size(); gi++) {
+        const size_t sel = si.selector_indices[gi];
+        K filter = compute_filter<K>(gi, si.groups[sel], local_constants[sel], nsel > 1);
+        size_t nc = gate_num_constraints(si.gates[gi]);
+        switch (si.gates[gi]) {
+            case GATE_NOOP: break;
+            case GATE_CONSTANT: eval_constant<K>(gc, wires, tmp); break;
+            case GATE_PUBLIC_INPUT: eval_public_input<K>(pi_hash, wires, tmp); break;
+            case GATE_ARITHMETIC: eval_arithmetic<K>(gc, wires, tmp); break;
+            default: eval_poseidon<K>(wires, tmp); break;
+        }
+        for (size_t j = 0; j < nc; j++) out[j] = kadd(out[j], kmul(filter, tmp[j]));
+    }
+}
+
+}  // namespace orc

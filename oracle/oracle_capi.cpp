@@ -1,7 +1,7 @@
 // ORACLE (test infrastructure only): flat C entry points over the CPU restatement so that tests/,
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg can drive it through ctypes.
 // The product library (libplonky2_mi355x.so) never links or loads this file.
-#include "gl_batch.hpp"
+#include "gl_prover.hpp"
 #include <cstring>
 
 using namespace orc;
@@ -179,5 +179,126 @@ size_t orc_batch_prove(const void* b, size_t leaf_index, u64* out) {
 }
 size_t orc_batch_num_levels(const void* b) { return ((const PolynomialBatch*)b)->tree.levels.size(); }
 void orc_batch_level(const void* b, size_t level, u64* out) { write_digests(((const PolynomialBatch*)b)->tree.levels[level], out); }
+
+
+// ---- matmul circuit / witness / prover / verifier ------------------------------------------------------
+struct OrcProof { Proof proof; ProverTrace trace; std::vector<uint8_t> bytes; };
+
+void* orc_circuit_new(size_t m, unsigned threads) { return new CircuitData(build_matmul_circuit(m, threads)); }
+void orc_circuit_free(void* c) { delete (CircuitData*)c; }
+// out: [degree_bits, num_constants, num_gate_constraints, num_partial_products, num_public_inputs, num_selectors,
+//       num_fri_rounds, final_poly_len, pi_row, constant_row, num_arith_ops, num_poseidon_rows]
+void orc_circuit_info(const void* c, u64* out) {
+    const CircuitData* cd = (const CircuitData*)c;
+    const CommonData& cm = cd->common;
+    u64 v[12] = {cm.degree_bits, cm.num_constants, cm.num_gate_constraints, cm.num_partial_products, cm.num_public_inputs,
+                 cm.selectors.num_selectors(), cm.fri_reduction_arity_bits.size(), cm.final_poly_len(), cd->pi_row, cd->constant_row,
+                 cd->arith_ops.size(), cd->poseidon_rows.size()};
+    memcpy(out, v, sizeof v);
+}
+void orc_circuit_digest(const void* c, u64* out4) { for (int i = 0; i < 4; i++) out4[i] = canon(((const CircuitData*)c)->circuit_digest.e[i]); }
+void orc_circuit_cs_cap(const void* c, u64* out) { write_digests(((const CircuitData*)c)->constants_sigmas_commitment.tree.cap(), out); }
+void orc_circuit_constants_sigmas(const void* c, u64* out) {
+    const CircuitData* cd = (const CircuitData*)c; size_t n = cd->common.degree();
+    for (size_t k = 0; k < cd->constants_sigmas.size(); k++) for (size_t i = 0; i < n; i++) out[k * n + i] = canon(cd->constants_sigmas[k][i]);
+}
+void orc_circuit_row_gates(const void* c, uint8_t* out) {
+    const CircuitData* cd = (const CircuitData*)c;
+    for (size_t i = 0; i < cd->row_gate.size(); i++) out[i] = (uint8_t)cd->row_gate[i];
+}
+// gate order used by the selectors (sorted by (degree, id)), as GateType codes
+size_t orc_circuit_gate_order(const void* c, uint8_t* out) {
+    const CircuitData* cd = (const CircuitData*)c;
+    for (size_t i = 0; i < cd->common.selectors.gates.size(); i++) out[i] = (uint8_t)cd->common.selectors.gates[i];
+    return cd->common.selectors.gates.size();
+}
+void* orc_witness_new(const void* c, const u64* a, const u64* b, u64 filler_seed) {
+    const CircuitData* cd = (const CircuitData*)c; size_t mm = cd->m * cd->m;
+    return new Witness(generate_witness(*cd, std::vector<u64>(a, a + mm), std::vector<u64>(b, b + mm), filler_seed));
+}
+void orc_witness_free(void* w) { delete (Witness*)w; }
+void orc_witness_wires(const void* w, u64* out) {
+    const Witness* wt = (const Witness*)w; size_t n = wt->wire_values[0].size();
+    for (size_t j = 0; j < wt->wire_values.size(); j++) memcpy(out + j * n, wt->wire_values[j].data(), n * 8);
+}
+size_t orc_witness_public_inputs(const void* w, u64* out) {
+    const Witness* wt = (const Witness*)w;
+    if (out) memcpy(out, wt->public_inputs.data(), wt->public_inputs.size() * 8);
+    return wt->public_inputs.size();
+}
+// a witness handle from an externally supplied wire matrix [135][n] + public inputs
+void* orc_witness_from_matrix(const u64* wires, size_t num_wires, size_t n, const u64* pis, size_t npis) {
+    Witness* w = new Witness();
+    w->wire_values.resize(num_wires);
+    for (size_t j = 0; j < num_wires; j++) w->wire_values[j].assign(wires + j * n, wires + (j + 1) * n);
+    w->public_inputs.assign(pis, pis + npis);
+    return w;
+}
+void* orc_prove(const void* c, const void* w, unsigned threads) {
+    OrcProof* p = new OrcProof();
+    if (!prove(*(const CircuitData*)c, *(const Witness*)w, threads, p->proof, &p->trace)) { delete p; return nullptr; }
+    p->bytes = proof_to_bytes(p->proof);
+    return p;
+}
+void orc_proof_free(void* p) { delete (OrcProof*)p; }
+size_t orc_proof_bytes(const void* p, uint8_t* out, size_t cap) {
+    const OrcProof* op = (const OrcProof*)p;
+    if (out && cap >= op->bytes.size()) memcpy(out, op->bytes.data(), op->bytes.size());
+    return op->bytes.size();
+}
+// out: betas[2] gammas[2] alphas[2] zeta[2] fri_alpha[2] pow_witness pi_hash[4] then fri_betas (2 each)
+size_t orc_proof_challenges(const void* p, u64* out) {
+    const OrcProof* op = (const OrcProof*)p; size_t k = 0;
+    for (u64 v : op->trace.betas) out[k++] = canon(v);
+    for (u64 v : op->trace.gammas) out[k++] = canon(v);
+    for (u64 v : op->trace.alphas) out[k++] = canon(v);
+    out[k++] = canon(op->trace.zeta.a); out[k++] = canon(op->trace.zeta.b);
+    out[k++] = canon(op->trace.fri_alpha.a); out[k++] = canon(op->trace.fri_alpha.b);
+    out[k++] = canon(op->proof.opening_proof.pow_witness);
+    for (int i = 0; i < 4; i++) out[k++] = canon(op->trace.public_inputs_hash.e[i]);
+    for (auto& b : op->trace.fri_betas) { out[k++] = canon(b.a); out[k++] = canon(b.b); }
+    return k;
+}
+void orc_proof_zs_partial_products(const void* p, u64* out) {
+    const OrcProof* op = (const OrcProof*)p; size_t n = op->trace.zs_partial_products[0].size();
+    for (size_t c = 0; c < op->trace.zs_partial_products.size(); c++) for (size_t i = 0; i < n; i++) out[c * n + i] = canon(op->trace.zs_partial_products[c][i]);
+}
+void orc_proof_quotient_chunks(const void* p, u64* out) {
+    const OrcProof* op = (const OrcProof*)p; size_t n = op->trace.quotient_chunks[0].size();
+    for (size_t c = 0; c < op->trace.quotient_chunks.size(); c++) for (size_t i = 0; i < n; i++) out[c * n + i] = canon(op->trace.quotient_chunks[c][i]);
+}
+void orc_proof_caps(const void* p, u64* out) {          // wires, zs_pp, quotient: 3 x 16 x 4
+    const OrcProof* op = (const OrcProof*)p;
+    write_digests(op->proof.wires_cap, out); write_digests(op->proof.zs_pp_cap, out + 64); write_digests(op->proof.quotient_cap, out + 128);
+}
+size_t orc_proof_query_indices(const void* p, u64* out) {
+    const OrcProof* op = (const OrcProof*)p;
+    for (size_t i = 0; i < op->trace.query_indices.size(); i++) out[i] = op->trace.query_indices[i];
+    return op->trace.query_indices.size();
+}
+void orc_proof_final_poly_initial(const void* p, u64* out) {
+    const OrcProof* op = (const OrcProof*)p;
+    for (size_t i = 0; i < op->trace.final_poly_coeffs_initial.size(); i++) { out[2 * i] = canon(op->trace.final_poly_coeffs_initial[i].a); out[2 * i + 1] = canon(op->trace.final_poly_coeffs_initial[i].b); }
+}
+static thread_local const char* g_verify_msg = "";
+// 0 = accepted
+int orc_verify(const void* c, const void* p) {
+    const char* m = verify(*(const CircuitData*)c, ((const OrcProof*)p)->proof);
+    g_verify_msg = m ? m : "";
+    return m ? 1 : 0;
+}
+const char* orc_verify_message(void) { return g_verify_msg; }
+// flips one byte-level component of the proof (test helper for verifier soundness smoke checks)
+void orc_proof_tamper(void* p, int what) {
+    OrcProof* op = (OrcProof*)p;
+    switch (what) {
+        case 0: op->proof.openings.wires[3].a = add(op->proof.openings.wires[3].a, 1); break;
+        case 1: op->proof.opening_proof.pow_witness += 1; break;
+        case 2: op->proof.opening_proof.final_poly[0].b = add(op->proof.opening_proof.final_poly[0].b, 1); break;
+        case 3: op->proof.public_inputs[0] = add(op->proof.public_inputs[0], 1); break;
+        case 4: op->proof.opening_proof.query_round_proofs[5].initial[1].first[7] = add(op->proof.opening_proof.query_round_proofs[5].initial[1].first[7], 1); break;
+        case 5: op->proof.quotient_cap[2].e[1] = add(op->proof.quotient_cap[2].e[1], 1); break;
+    }
+}
 
 }  // extern "C"

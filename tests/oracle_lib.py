@@ -122,6 +122,9 @@ class Oracle:
     def batch(self, cols, rate_bits, cap_height, from_values=True, threads=1):
         return OracleBatch(self, cols, rate_bits, cap_height, from_values, threads)
 
+    def circuit(self, m, threads=1):
+        return OracleCircuit(self, m, threads)
+
 
 class OracleMerkle:
     def __init__(self, o, leaves, cap_height):
@@ -188,6 +191,155 @@ class OracleBatch:
     def __del__(self):
         try:
             self.o.lib.orc_batch_free(self.h)
+        except Exception:
+            pass
+
+
+class OracleCircuit:
+    """build_matmul_circuit + witness + prove + verify of the CPU restatement (oracle/gl_circuit.hpp, gl_prover.hpp)."""
+    INFO = ["degree_bits", "num_constants", "num_gate_constraints", "num_partial_products", "num_public_inputs",
+            "num_selectors", "num_fri_rounds", "final_poly_len", "pi_row", "constant_row", "num_arith_ops", "num_poseidon_rows"]
+
+    def __init__(self, o, m, threads=1):
+        self.o, self.m = o, m
+        lib = o.lib
+        lib.orc_circuit_new.restype = _vp
+        lib.orc_witness_new.restype = _vp
+        lib.orc_witness_from_matrix.restype = _vp
+        lib.orc_prove.restype = _vp
+        lib.orc_proof_bytes.restype = _sz
+        lib.orc_proof_challenges.restype = _sz
+        lib.orc_proof_query_indices.restype = _sz
+        lib.orc_witness_public_inputs.restype = _sz
+        lib.orc_circuit_gate_order.restype = _sz
+        lib.orc_verify_message.restype = ctypes.c_char_p
+        self.h = _vp(lib.orc_circuit_new(_sz(m), _u32(threads)))
+        info = np.zeros(12, dtype=np.uint64)
+        lib.orc_circuit_info(self.h, _p(info))
+        self.info = dict(zip(self.INFO, (int(x) for x in info)))
+        self.n = 1 << self.info["degree_bits"]
+
+    @property
+    def digest(self):
+        out = np.empty(4, dtype=np.uint64)
+        self.o.lib.orc_circuit_digest(self.h, _p(out))
+        return out
+
+    @property
+    def constants_sigmas_cap(self):
+        out = np.empty((16, 4), dtype=np.uint64)
+        self.o.lib.orc_circuit_cs_cap(self.h, _p(out))
+        return out
+
+    def constants_sigmas(self):
+        out = np.empty((self.info["num_constants"] + 80, self.n), dtype=np.uint64)
+        self.o.lib.orc_circuit_constants_sigmas(self.h, _p(out))
+        return out
+
+    def row_gates(self):
+        out = np.empty(self.n, dtype=np.uint8)
+        self.o.lib.orc_circuit_row_gates(self.h, _p(out))
+        return out
+
+    def gate_order(self):
+        out = np.empty(8, dtype=np.uint8)
+        k = self.o.lib.orc_circuit_gate_order(self.h, _p(out))
+        return out[:k].tolist()
+
+    def witness(self, a, b, filler_seed=0x504C4F4E4B5932):
+        return OracleWitness(self, u64(a).reshape(-1), u64(b).reshape(-1), filler_seed)
+
+    def __del__(self):
+        try:
+            self.o.lib.orc_circuit_free(self.h)
+        except Exception:
+            pass
+
+
+class OracleWitness:
+    def __init__(self, circuit, a, b, seed):
+        self.c = circuit
+        lib = circuit.o.lib
+        assert a.size == circuit.m ** 2 and b.size == circuit.m ** 2
+        self.h = _vp(lib.orc_witness_new(circuit.h, _p(a), _p(b), _u64(seed)))
+
+    def wires(self):
+        out = np.empty((135, self.c.n), dtype=np.uint64)
+        self.c.o.lib.orc_witness_wires(self.h, _p(out))
+        return out
+
+    def public_inputs(self):
+        k = self.c.o.lib.orc_witness_public_inputs(self.h, None)
+        out = np.empty(k, dtype=np.uint64)
+        self.c.o.lib.orc_witness_public_inputs(self.h, _p(out))
+        return out
+
+    def prove(self, threads=1):
+        h = self.c.o.lib.orc_prove(self.c.h, self.h, _u32(threads))
+        if not h:
+            raise RuntimeError("oracle prover failed (quotient not divisible or zeta in H)")
+        return OracleProof(self.c, _vp(h))
+
+    def __del__(self):
+        try:
+            self.c.o.lib.orc_witness_free(self.h)
+        except Exception:
+            pass
+
+
+class OracleProof:
+    def __init__(self, circuit, h):
+        self.c, self.h = circuit, h
+
+    def to_bytes(self):
+        lib = self.c.o.lib
+        k = lib.orc_proof_bytes(self.h, None, _sz(0))
+        buf = np.empty(k, dtype=np.uint8)
+        lib.orc_proof_bytes(self.h, _p(buf), _sz(k))
+        return buf.tobytes()
+
+    def challenges(self):
+        out = np.zeros(64, dtype=np.uint64)
+        k = self.c.o.lib.orc_proof_challenges(self.h, _p(out))
+        v = [int(x) for x in out[:k]]
+        return {"betas": v[0:2], "gammas": v[2:4], "alphas": v[4:6], "zeta": v[6:8], "fri_alpha": v[8:10], "pow_witness": v[10],
+                "public_inputs_hash": v[11:15], "fri_betas": [v[i:i + 2] for i in range(15, k, 2)]}
+
+    def caps(self):
+        out = np.empty((3, 16, 4), dtype=np.uint64)
+        self.c.o.lib.orc_proof_caps(self.h, _p(out))
+        return out
+
+    def zs_partial_products(self):
+        out = np.empty((20, self.c.n), dtype=np.uint64)
+        self.c.o.lib.orc_proof_zs_partial_products(self.h, _p(out))
+        return out
+
+    def quotient_chunks(self):
+        out = np.empty((16, self.c.n), dtype=np.uint64)
+        self.c.o.lib.orc_proof_quotient_chunks(self.h, _p(out))
+        return out
+
+    def final_poly_initial(self):
+        out = np.empty((self.c.n, 2), dtype=np.uint64)
+        self.c.o.lib.orc_proof_final_poly_initial(self.h, _p(out))
+        return out
+
+    def query_indices(self):
+        out = np.zeros(64, dtype=np.uint64)
+        k = self.c.o.lib.orc_proof_query_indices(self.h, _p(out))
+        return [int(x) for x in out[:k]]
+
+    def verify(self):
+        r = self.c.o.lib.orc_verify(self.c.h, self.h)
+        return r == 0, self.c.o.lib.orc_verify_message().decode()
+
+    def tamper(self, what):
+        self.c.o.lib.orc_proof_tamper(self.h, what)
+
+    def __del__(self):
+        try:
+            self.c.o.lib.orc_proof_free(self.h)
         except Exception:
             pass
 

@@ -140,3 +140,68 @@ def test_polynomial_batch_python_model(orc, golden):
     b9 = orc.batch(np.array(m9["values"], dtype=np.uint64), m9["rate_bits"], m9["cap_height"], from_values=True, threads=2)
     assert b9.cap.tolist() == m9["cap"]
     assert b9.prove(37).tolist() == m9["path_37"]
+
+
+# ------------------------------------------------------------------------------------------ whole prover
+def test_matmul_circuit_shapes(orc):
+    # row counts before padding (README.md worked instance): m=2 -> 6 rows, m=20 -> 932 rows
+    c2 = orc.circuit(2)
+    assert c2.info["degree_bits"] == 3 and c2.info["num_arith_ops"] == 12 and c2.info["num_poseidon_rows"] == 2
+    assert c2.info["pi_row"] == 4 and c2.info["constant_row"] == 5           # 2 arithmetic + 2 Poseidon rows first
+    assert c2.gate_order() == [0, 1, 2, 3, 4]                                # Noop, Constant, PublicInput, Arithmetic, Poseidon
+    assert c2.info["num_constants"] == 4 and c2.info["num_selectors"] == 2   # selectors.rs greedy grouping, max degree 9
+    assert c2.info["num_gate_constraints"] == 123 and c2.info["num_partial_products"] == 9
+    c20 = orc.circuit(20, threads=4)
+    assert c20.info["pi_row"] == 930 and c20.info["constant_row"] == 931 and c20.info["degree_bits"] == 10
+    assert c20.info["num_fri_rounds"] == 2 and c20.info["final_poly_len"] == 4
+    cs = c2.constants_sigmas()
+    # selector columns: group 0 holds gate indices 0..3, UNUSED elsewhere; constants of arithmetic rows are (1,0)/(1,1)
+    gates = c2.row_gates().tolist()
+    assert gates == [3, 3, 4, 4, 2, 1, 0, 0]
+    U = 0xFFFFFFFF
+    assert cs[0].tolist() == [3, 3, U, U, 2, 1, 0, 0] and cs[1].tolist() == [U, U, 4, 4, U, U, U, U]
+    assert cs[2].tolist()[:2] == [1, 1] and cs[3].tolist()[:2] == [0, 1] and cs[2][5] == 0 and cs[3][5] == 1
+    # every sigma column is a permutation image: the multiset {sigma values} equals {k_j * w^i}
+    n, w = 8, orc.primitive_root(3)
+    ids = sorted(pow(7, j, P) * pow(w, i, P) % P for j in range(80) for i in range(n))
+    assert sorted(int(x) for x in cs[4:].reshape(-1)) == ids
+
+
+def test_readme_instance_m2_proves_and_verifies(orc):
+    # README.md:74-84 / matrix_mul.rs:74: A = [[1,2],[3,4]], B = [[5,6],[7,8]]
+    c = orc.circuit(2)
+    w = c.witness([1, 2, 3, 4], [5, 6, 7, 8])
+    pis = w.public_inputs().reshape(-1, 3)
+    assert pis.tolist() == [[1, 5, 19], [2, 6, 22], [3, 7, 43], [4, 8, 50]]     # (a_ij, b_ij, c_ij)
+    wires = w.wires()
+    assert wires.shape == (135, 8)
+    assert wires[:, 6].tolist() == [0] * 135 and wires[:, 7].tolist() == [0] * 135   # Noop rows
+    proof = w.prove()
+    ok, msg = proof.verify()
+    assert ok, msg
+    assert len(proof.to_bytes()) == 70288
+    ch = proof.challenges()
+    assert ch["fri_betas"] == [] and len(proof.query_indices()) == 28
+    # deterministic: same witness matrix -> same bytes; different filler wires -> different proof, same public inputs
+    assert proof.to_bytes() == w.prove().to_bytes()
+    w2 = c.witness([1, 2, 3, 4], [5, 6, 7, 8], filler_seed=7)
+    p2 = w2.prove()
+    assert p2.to_bytes() != proof.to_bytes() and p2.verify()[0]
+
+
+def test_prover_with_fri_rounds_and_tampering(orc):
+    c = orc.circuit(8, threads=4)                      # n = 2^7, one arity-16 FRI round, final poly of 8
+    assert c.info["num_fri_rounds"] == 1
+    a, b = rand_field(8, 64) % (2**32 - 1), rand_field(9, 64) % (2**32 - 1)
+    w = c.witness(a, b)
+    A, B = [[int(x) for x in r] for r in a.reshape(8, 8)], [[int(x) for x in r] for r in b.reshape(8, 8)]
+    C = [[sum(A[i][k] * B[k][j] for k in range(8)) % P for j in range(8)] for i in range(8)]
+    assert w.public_inputs().reshape(64, 3)[:, 2].tolist() == [C[i][j] for i in range(8) for j in range(8)]
+    proof = w.prove(threads=4)
+    assert proof.verify()[0]
+    assert proof.to_bytes() == w.prove(threads=1).to_bytes()       # thread count does not change the proof
+    for what, needle in ((0, "vanishing"), (1, "proof of work"), (3, "vanishing"), (4, "Merkle"), (5, "vanishing")):
+        bad = w.prove(threads=4)
+        bad.tamper(what)
+        ok, msg = bad.verify()
+        assert not ok and needle in msg, (what, msg)
