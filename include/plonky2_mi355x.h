@@ -43,6 +43,33 @@ extern "C" {
 typedef struct gl_ctx gl_ctx;
 typedef struct gl_batch gl_batch;      /* device-resident PolynomialBatch (fri/oracle.rs:30-37)  */
 typedef struct gl_merkle gl_merkle;    /* device-resident MerkleTree (hash/merkle_tree.rs:39-55) */
+typedef struct gl_host_circuit gl_host_circuit;   /* host-only circuit description + witness recipe        */
+typedef struct gl_circuit gl_circuit;  /* device-resident prover data (ProverOnlyCircuitData + CommonCircuitData) */
+typedef struct gl_proof gl_proof;      /* ProofWithPublicInputs + the prover's intermediate values              */
+
+/* What prove() needs from CommonCircuitData / ProverOnlyCircuitData (plonky2/src/plonk/circuit_data.rs:240-330,
+ * 380-440) besides the constants/sigma value columns.  Gate types: 0 Noop, 1 Constant, 2 PublicInput,
+ * 3 Arithmetic(20 ops), 4 Poseidon -- the gate set of the matmul demo circuit; `gate_types` is the list
+ * `common_data.gates` (sorted by degree, id) and the group arrays are `selectors_info`
+ * (plonky2/src/gates/selectors.rs:17-26). */
+typedef struct gl_circuit_desc {
+    uint32_t degree_bits;              /* log2 of the trace length n                                */
+    uint32_t num_wires;                /* 135                                                       */
+    uint32_t num_routed_wires;         /* 80                                                        */
+    uint32_t num_constants;            /* selector columns + gate-constant columns (4)              */
+    uint32_t num_selectors;            /* 2                                                         */
+    uint32_t num_challenges;           /* 2                                                         */
+    uint32_t quotient_degree_factor;   /* 8                                                         */
+    uint32_t rate_bits, cap_height, proof_of_work_bits, num_query_rounds;
+    uint32_t num_fri_rounds;           /* reduction_arity_bits.len()                                */
+    uint32_t fri_arity_bits[8];
+    uint32_t num_public_inputs;
+    uint32_t num_gates;
+    uint8_t gate_types[8];
+    uint32_t gate_selector_index[8];
+    uint32_t gate_group_start[8], gate_group_end[8];
+    uint64_t k_is[80];                 /* coset shifts 7^j (field/src/cosets.rs:9-24)               */
+} gl_circuit_desc;
 
 /* ---- context ------------------------------------------------------------------------------------ */
 /* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL to let
@@ -138,6 +165,50 @@ size_t gl_batch_degree(const gl_batch* b);
 const uint64_t* gl_batch_dev_coeffs(const gl_batch* b);   /* d [ncols][n]  */
 const uint64_t* gl_batch_dev_lde(const gl_batch* b);      /* d [ncols][N]  */
 void gl_batch_free(gl_batch* b);
+
+/* ---- circuit data ----------------------------------------------------------------------------------*/
+/* Host side of the demo (no GPU needed): the matmul circuit of plonky2/src/bin/matrix_mul.rs:25-67 after
+ * CircuitBuilder::build() (plonk/circuit_builder.rs:913-1146): descriptor, gate type per row, and the
+ * constants || sigmas VALUE columns, h_out[(num_constants + 80)][n]. */
+int gl_matmul_circuit_build(size_t m, gl_host_circuit** out);
+int gl_host_circuit_desc(const gl_host_circuit* hc, gl_circuit_desc* out);
+int gl_host_circuit_row_gates(const gl_host_circuit* hc, uint8_t* h_out /* n */);
+int gl_host_circuit_constants_sigmas(const gl_host_circuit* hc, uint64_t* h_out);
+/* generate_partial_witness + full_witness (plonk/prover.rs:118-133) for this circuit: a, b row-major m x m;
+ * the 131 values the reference draws from OsRng for the unused PublicInputGate wires
+ * (circuit_builder.rs:904-910) come from splitmix64(filler_seed).  h_wires[135][n], h_public_inputs[3 m^2]. */
+int gl_matmul_witness(const gl_host_circuit* hc, const uint64_t* h_a, const uint64_t* h_b, uint64_t filler_seed,
+                      uint64_t* h_wires, uint64_t* h_public_inputs);
+void gl_host_circuit_free(gl_host_circuit* hc);
+
+/* The device half of build(): PolynomialBatch::from_values(constants || sigmas) (circuit_builder.rs:1020-1028),
+ * circuit_digest (:1089-1100), sigma / subgroup tables.  h_constants_sigmas[(num_constants + 80)][n]. */
+int gl_circuit_create(gl_ctx* ctx, const gl_circuit_desc* desc, const uint64_t* h_constants_sigmas, gl_circuit** out);
+int gl_circuit_from_host(gl_ctx* ctx, const gl_host_circuit* hc, gl_circuit** out);
+int gl_circuit_digest(const gl_circuit* c, uint64_t h_out[4]);                 /* verifier_only.circuit_digest */
+int gl_circuit_constants_sigmas_cap(const gl_circuit* c, uint64_t* h_out);     /* [2^cap_height][4]            */
+const gl_batch* gl_circuit_constants_sigmas_batch(const gl_circuit* c);
+void gl_circuit_free(gl_circuit* c);
+
+/* ---- prove() ---------------------------------------------------------------------------------------*/
+/* plonk::prover::prove (plonky2/src/plonk/prover.rs:102-329) from step 4 on, i.e. given the FULL witness matrix
+ * `MatrixWitness.wire_values` (iop/witness.rs:256-258) h_wires[num_wires][n] and the public inputs.  Every
+ * polynomial stays device-resident; the host only sees Merkle caps, openings and query answers.  The PoW
+ * witness is the smallest valid one (the 1-thread order of fri/prover.rs:141-152).
+ * Returns GL_ERR_ZETA_IN_SUBGROUP for prover.rs:280-283. */
+int gl_prove(gl_ctx* ctx, const gl_circuit* c, const uint64_t* h_wires, const uint64_t* h_public_inputs,
+             size_t num_public_inputs, gl_proof** out);
+/* ProofWithPublicInputs::to_bytes (plonk/proof.rs:104-110; util/serialization/mod.rs:1939-1981) */
+size_t gl_proof_num_bytes(const gl_proof* p);
+int gl_proof_bytes(const gl_proof* p, uint8_t* h_out, size_t cap);
+/* intermediates, for parity tests: betas[2] gammas[2] alphas[2] zeta[2] fri_alpha[2] pow_witness pi_hash[4],
+ * then the FRI betas (2 words each); returns the number of words written */
+size_t gl_proof_challenges(const gl_proof* p, uint64_t* h_out);
+int gl_proof_caps(const gl_proof* p, uint64_t* h_out /* [3][2^cap_height][4]: wires, zs_pp, quotient */);
+int gl_proof_zs_partial_products(const gl_proof* p, uint64_t* h_out /* [20][n] values */);
+int gl_proof_quotient_chunks(const gl_proof* p, uint64_t* h_out /* [16][n] coefficients */);
+size_t gl_proof_query_indices(const gl_proof* p, uint64_t* h_out);
+void gl_proof_free(gl_proof* p);
 
 #ifdef __cplusplus
 }

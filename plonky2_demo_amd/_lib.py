@@ -79,7 +79,40 @@ SIGNATURES = {
     "gl_batch_dev_coeffs": (c_vp, [c_vp]),
     "gl_batch_dev_lde": (c_vp, [c_vp]),
     "gl_batch_free": (None, [c_vp]),
+    "gl_matmul_circuit_build": (c_int, [c_sz, ctypes.POINTER(c_vp)]),
+    "gl_host_circuit_desc": (c_int, [c_vp, c_vp]),
+    "gl_host_circuit_row_gates": (c_int, [c_vp, c_vp]),
+    "gl_host_circuit_constants_sigmas": (c_int, [c_vp, c_vp]),
+    "gl_matmul_witness": (c_int, [c_vp, c_vp, c_vp, c_u64, c_vp, c_vp]),
+    "gl_host_circuit_free": (None, [c_vp]),
+    "gl_circuit_create": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(c_vp)]),
+    "gl_circuit_from_host": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
+    "gl_circuit_digest": (c_int, [c_vp, c_vp]),
+    "gl_circuit_constants_sigmas_cap": (c_int, [c_vp, c_vp]),
+    "gl_circuit_constants_sigmas_batch": (c_vp, [c_vp]),
+    "gl_circuit_free": (None, [c_vp]),
+    "gl_prove": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "gl_proof_num_bytes": (c_sz, [c_vp]),
+    "gl_proof_bytes": (c_int, [c_vp, c_vp, c_sz]),
+    "gl_proof_challenges": (c_sz, [c_vp, c_vp]),
+    "gl_proof_caps": (c_int, [c_vp, c_vp]),
+    "gl_proof_zs_partial_products": (c_int, [c_vp, c_vp]),
+    "gl_proof_quotient_chunks": (c_int, [c_vp, c_vp]),
+    "gl_proof_query_indices": (c_sz, [c_vp, c_vp]),
+    "gl_proof_free": (None, [c_vp]),
 }
+
+
+class CircuitDesc(ctypes.Structure):
+    """gl_circuit_desc (include/plonky2_mi355x.h)."""
+    _fields_ = [
+        ("degree_bits", c_u32), ("num_wires", c_u32), ("num_routed_wires", c_u32), ("num_constants", c_u32),
+        ("num_selectors", c_u32), ("num_challenges", c_u32), ("quotient_degree_factor", c_u32),
+        ("rate_bits", c_u32), ("cap_height", c_u32), ("proof_of_work_bits", c_u32), ("num_query_rounds", c_u32),
+        ("num_fri_rounds", c_u32), ("fri_arity_bits", c_u32 * 8), ("num_public_inputs", c_u32), ("num_gates", c_u32),
+        ("gate_types", ctypes.c_uint8 * 8), ("gate_selector_index", c_u32 * 8),
+        ("gate_group_start", c_u32 * 8), ("gate_group_end", c_u32 * 8), ("k_is", c_u64 * 80),
+    ]
 
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)   # AttributeError here = the .so does not export a declared symbol

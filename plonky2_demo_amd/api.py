@@ -110,6 +110,9 @@ def default_context():
     global _default
     if _default is None:
         _default = Context(0)
+        # handles created on the default context may be finalised in any order at interpreter exit:
+        # never tear the shared context down under them (the process is ending anyway)
+        _default.close = lambda: None
     return _default
 
 
@@ -349,5 +352,137 @@ class PolynomialBatch:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------- circuit and prove()
+class MatmulCircuit:
+    """Host side of the demo (plonky2/src/bin/matrix_mul.rs:25-67 + CircuitBuilder::build()): needs no GPU."""
+
+    def __init__(self, m):
+        h = ctypes.c_void_p()
+        check(lib.gl_matmul_circuit_build(int(m), ctypes.byref(h)))
+        self.handle, self.m = h.value, int(m)
+        self.desc = _lib.CircuitDesc()
+        check(lib.gl_host_circuit_desc(self.handle, ctypes.byref(self.desc)))
+        self.degree_bits = self.desc.degree_bits
+        self.n = 1 << self.degree_bits
+
+    def row_gates(self):
+        out = np.empty(self.n, dtype=np.uint8)
+        check(lib.gl_host_circuit_row_gates(self.handle, _p(out)))
+        return out
+
+    def constants_sigmas(self):
+        out = np.empty((self.desc.num_constants + 80, self.n), dtype=np.uint64)
+        check(lib.gl_host_circuit_constants_sigmas(self.handle, _p(out)))
+        return out
+
+    def witness(self, a, b, filler_seed=0x504C4F4E4B5932):
+        """(wires[135][n], public_inputs[3 m^2]) -- generate_partial_witness + full_witness (prover.rs:118-133)."""
+        a, b = _u64(a).reshape(-1), _u64(b).reshape(-1)
+        if a.size != self.m ** 2 or b.size != self.m ** 2:
+            raise ValueError("a and b must be m x m")
+        wires = np.empty((135, self.n), dtype=np.uint64)
+        pis = np.empty(3 * self.m ** 2, dtype=np.uint64)
+        check(lib.gl_matmul_witness(self.handle, _p(a), _p(b), filler_seed, _p(wires), _p(pis)))
+        return wires, pis
+
+    def build(self, ctx=None):
+        """CircuitBuilder::build(): the device half (constants/sigmas commitment, digest)."""
+        return CircuitData(self, _ctx(ctx))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.gl_host_circuit_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class CircuitData:
+    """plonky2::plonk::circuit_data::CircuitData for the prover: `prove(wires, public_inputs)` mirrors
+    CircuitData::prove (circuit_data.rs:144-151) at the full-witness boundary."""
+
+    def __init__(self, host, ctx):
+        self.host, self.ctx = host, ctx
+        h = ctypes.c_void_p()
+        check(lib.gl_circuit_from_host(ctx.handle, host.handle, ctypes.byref(h)))
+        self.handle = h.value
+
+    @property
+    def circuit_digest(self):
+        out = np.empty(4, dtype=np.uint64)
+        check(lib.gl_circuit_digest(self.handle, _p(out)))
+        return out
+
+    @property
+    def constants_sigmas_cap(self):
+        out = np.empty((1 << self.host.desc.cap_height, 4), dtype=np.uint64)
+        check(lib.gl_circuit_constants_sigmas_cap(self.handle, _p(out)))
+        return out
+
+    def prove(self, wires, public_inputs):
+        wires, pis = _u64(wires), _u64(public_inputs)
+        if wires.shape != (135, self.host.n):
+            raise ValueError("wire matrix must be [135][n]")
+        h = ctypes.c_void_p()
+        check(lib.gl_prove(self.ctx.handle, self.handle, _p(wires), _p(pis), pis.size, ctypes.byref(h)))
+        return Proof(h.value, self.host.n)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.gl_circuit_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class Proof:
+    def __init__(self, handle, n):
+        self.handle, self.n = handle, n
+
+    def to_bytes(self):
+        """ProofWithPublicInputs::to_bytes (plonk/proof.rs:104-110)."""
+        k = lib.gl_proof_num_bytes(self.handle)
+        buf = np.empty(k, dtype=np.uint8)
+        check(lib.gl_proof_bytes(self.handle, _p(buf), k))
+        return buf.tobytes()
+
+    def challenges(self):
+        out = np.zeros(64, dtype=np.uint64)
+        k = lib.gl_proof_challenges(self.handle, _p(out))
+        v = [int(x) for x in out[:k]]
+        return {"betas": v[0:2], "gammas": v[2:4], "alphas": v[4:6], "zeta": v[6:8], "fri_alpha": v[8:10], "pow_witness": v[10],
+                "public_inputs_hash": v[11:15], "fri_betas": [v[i:i + 2] for i in range(15, k, 2)]}
+
+    def caps(self):
+        out = np.empty((3, 16, 4), dtype=np.uint64)
+        check(lib.gl_proof_caps(self.handle, _p(out)))
+        return out
+
+    def zs_partial_products(self):
+        out = np.empty((20, self.n), dtype=np.uint64)
+        check(lib.gl_proof_zs_partial_products(self.handle, _p(out)))
+        return out
+
+    def quotient_chunks(self):
+        out = np.empty((16, self.n), dtype=np.uint64)
+        check(lib.gl_proof_quotient_chunks(self.handle, _p(out)))
+        return out
+
+    def query_indices(self):
+        out = np.zeros(256, dtype=np.uint64)
+        k = lib.gl_proof_query_indices(self.handle, _p(out))
+        return [int(x) for x in out[:k]]
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.gl_proof_free(self.handle)
+                self.handle = None
         except Exception:
             pass

@@ -9,17 +9,6 @@
 #include "context.hpp"
 #include <cstring>
 
-int gl_merkle_prove_impl(gl_ctx* c, const GlMerkle& m, size_t leaf_index, uint64_t* h_out, uint32_t* n_siblings);
-
-struct gl_batch {
-    gl_ctx* ctx = nullptr;
-    size_t ncols = 0, n = 0;
-    uint32_t degree_log = 0, rate_bits = 0, cap_height = 0;
-    gl_t* coeffs = nullptr;
-    gl_t* lde = nullptr;
-    GlMerkle tree;
-    size_t N() const { return n << rate_bits; }
-};
 
 static int batch_commit(gl_ctx* c, gl_batch* b, bool is_values) {
     // values -> coefficients (oracle.rs:51-55), in place on the device copy

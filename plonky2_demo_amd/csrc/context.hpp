@@ -96,3 +96,15 @@ struct GlMerkle {
 int gl_merkle_build(gl_ctx* ctx, const gl_t* base, const uint64_t* host_offsets, uint32_t leaf_len,
                     uint32_t lg_leaves, uint32_t cap_height, GlMerkle* out);
 void gl_merkle_release(GlMerkle* m);
+int gl_merkle_prove_impl(gl_ctx* c, const GlMerkle& m, size_t leaf_index, uint64_t* h_out, uint32_t* n_siblings);
+
+// ---- PolynomialBatch (batch.hip) ------------------------------------------------------------------------
+struct gl_batch {
+    gl_ctx* ctx = nullptr;
+    size_t ncols = 0, n = 0;
+    uint32_t degree_log = 0, rate_bits = 0, cap_height = 0;
+    gl_t* coeffs = nullptr;      // [ncols][n]
+    gl_t* lde = nullptr;         // [ncols][N], natural order (index i <-> 7 * w_N^i)
+    GlMerkle tree;
+    size_t N() const { return n << rate_bits; }
+};

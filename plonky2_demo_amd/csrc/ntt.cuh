@@ -179,7 +179,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_col_pass(NttPassParams p) {
         const int e = tid + NTT_THREADS * q;
         const uint32_t t = e & (T - 1), i1 = e >> LOGT;
         const uint32_t i = (i1 << lgN2) + c0 + t;
-        v[q] = (i < p.n_in && !NTT_DBG(p, 2)) ? src[i] : (gl_t)e;
+        v[q] = NTT_DBG(p, 2) ? (gl_t)e : ((i < p.n_in) ? src[i] : (gl_t)0);
     }
 #pragma unroll
     for (int q = 0; q < NTT_EPT; q++) {

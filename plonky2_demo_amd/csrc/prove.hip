@@ -1,0 +1,562 @@
+// prove(): host driver replicating the phase order and Fiat-Shamir transcript of plonky2/src/plonk/prover.rs:102-329
+// with every polynomial-sized object resident in HBM.  The host sees only Merkle caps, openings, the final FRI
+// polynomial, the PoW witness and the query answers; each of those is a mandatory sync point because the next
+// phase's challenge is a Poseidon transcript of it (iop/challenger.rs:81-148).
+#include "context.hpp"
+#include "host_circuit.hpp"
+#include "prover_kernels.cuh"
+#include <cstring>
+#include <memory>
+
+using glhost::HostCircuit;
+
+struct gl_host_circuit { HostCircuit hc; };
+
+struct gl_circuit {
+    gl_ctx* ctx = nullptr;
+    gl_circuit_desc desc;
+    size_t n = 0;
+    gl_batch* cs_batch = nullptr;     // constants || sigmas commitment
+    gl_t* d_sigmas = nullptr;         // sigma VALUES [80][n]
+    gl_t circuit_digest[4];
+};
+
+struct gl_proof {
+    std::vector<uint8_t> bytes;
+    std::vector<gl_t> challenges;     // betas gammas alphas zeta fri_alpha pow pi_hash fri_betas...
+    std::vector<gl_t> caps;           // 3 x 16 x 4
+    std::vector<gl_t> zs_pp;          // [20][n]
+    std::vector<gl_t> quotient;       // [16][n]
+    std::vector<uint64_t> query_indices;
+};
+
+// ---- host Challenger (iop/challenger.rs:30-153) -----------------------------------------------------------------
+struct HostChallenger {
+    gl_t state[12]; gl_t in[8]; int nin = 0; gl_t out[8]; int nout = 0;
+    HostChallenger() { for (auto& s : state) s = 0; }
+    void duplexing() {
+        for (int i = 0; i < nin; i++) state[i] = in[i];
+        nin = 0;
+        psd_permute(state);
+        for (int i = 0; i < 8; i++) out[i] = state[i];
+        nout = 8;
+    }
+    void observe(gl_t x) { nout = 0; in[nin++] = x; if (nin == 8) duplexing(); }
+    void observe_many(const gl_t* v, size_t n) { for (size_t i = 0; i < n; i++) observe(v[i]); }
+    gl_t challenge() { if (nin || !nout) duplexing(); return gl_canon(out[--nout]); }
+};
+
+// ---- host circuit API ------------------------------------------------------------------------------------------------
+extern "C" int gl_matmul_circuit_build(size_t m, gl_host_circuit** out) {
+    GL_REQUIRE(out, GL_ERR_ARG, "null out");
+    std::unique_ptr<gl_host_circuit> h(new gl_host_circuit());
+    int st = glhost::build_matmul(m, &h->hc);
+    if (st != GL_OK) return gl_fail(st, "matmul dimension out of range (1..256)", __FILE__, __LINE__);
+    *out = h.release();
+    return GL_OK;
+}
+extern "C" int gl_host_circuit_desc(const gl_host_circuit* hc, gl_circuit_desc* out) {
+    GL_REQUIRE(hc && out, GL_ERR_ARG, "null argument");
+    *out = hc->hc.desc;
+    return GL_OK;
+}
+extern "C" int gl_host_circuit_row_gates(const gl_host_circuit* hc, uint8_t* h_out) {
+    GL_REQUIRE(hc && h_out, GL_ERR_ARG, "null argument");
+    memcpy(h_out, hc->hc.row_gate.data(), hc->hc.row_gate.size());
+    return GL_OK;
+}
+extern "C" int gl_host_circuit_constants_sigmas(const gl_host_circuit* hc, uint64_t* h_out) {
+    GL_REQUIRE(hc && h_out, GL_ERR_ARG, "null argument");
+    memcpy(h_out, hc->hc.constants_sigmas.data(), hc->hc.constants_sigmas.size() * sizeof(gl_t));
+    return GL_OK;
+}
+extern "C" int gl_matmul_witness(const gl_host_circuit* hc, const uint64_t* a, const uint64_t* b, uint64_t filler_seed, uint64_t* h_wires, uint64_t* h_pis) {
+    GL_REQUIRE(hc && a && b && h_wires && h_pis, GL_ERR_ARG, "null argument");
+    return glhost::matmul_witness(hc->hc, a, b, filler_seed, h_wires, h_pis);
+}
+extern "C" void gl_host_circuit_free(gl_host_circuit* hc) { delete hc; }
+
+// ---- device circuit -------------------------------------------------------------------------------------------------
+static int validate_desc(const gl_circuit_desc& d) {
+    GL_REQUIRE(d.num_wires == 135 && d.num_routed_wires == 80 && d.num_challenges == 2 && d.quotient_degree_factor == 8, GL_ERR_UNSUPPORTED,
+               "only standard_recursion_config (135 wires, 80 routed, 2 challenges, quotient factor 8) is supported");
+    GL_REQUIRE(d.rate_bits == 3, GL_ERR_UNSUPPORTED, "rate_bits must equal log2(quotient_degree_factor) = 3 (prover.rs:596-608 step = 1)");
+    GL_REQUIRE(d.cap_height <= d.degree_bits + d.rate_bits && d.degree_bits >= 1 && d.degree_bits + d.rate_bits <= 24, GL_ERR_ARG, "bad degree / cap height");
+    GL_REQUIRE(d.num_gates >= 1 && d.num_gates <= 8 && d.num_selectors >= 1 && d.num_selectors <= 4 && d.num_constants == d.num_selectors + 2, GL_ERR_ARG, "bad gate / selector description");
+    GL_REQUIRE(d.num_fri_rounds <= 8 && d.num_query_rounds >= 1 && d.num_query_rounds <= 256 && d.proof_of_work_bits <= 40, GL_ERR_ARG, "bad FRI parameters");
+    unsigned tot = 0;
+    for (unsigned r = 0; r < d.num_fri_rounds; r++) { GL_REQUIRE(d.fri_arity_bits[r] == 4, GL_ERR_UNSUPPORTED, "FRI arity must be 16"); tot += 4; }
+    GL_REQUIRE(tot <= d.degree_bits && d.degree_bits + d.rate_bits >= tot + d.cap_height, GL_ERR_ARG, "FRI total reduction arity is too large");   // circuit_builder.rs:977-980
+    for (unsigned g = 0; g < d.num_gates; g++) {
+        GL_REQUIRE(d.gate_types[g] <= 4, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon}");
+        GL_REQUIRE(d.gate_selector_index[g] < d.num_selectors && d.gate_group_start[g] <= g && g < d.gate_group_end[g] && d.gate_group_end[g] <= d.num_gates, GL_ERR_ARG, "bad selector group");
+    }
+    return GL_OK;
+}
+
+extern "C" void gl_circuit_free(gl_circuit* c) {
+    if (!c) return;
+    if (c->cs_batch) gl_batch_free(c->cs_batch);
+    if (c->d_sigmas) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); (void)hipFree(c->d_sigmas); }
+    delete c;
+}
+
+extern "C" int gl_circuit_create(gl_ctx* ctx, const gl_circuit_desc* desc, const uint64_t* h_cs, gl_circuit** out) {
+    GL_REQUIRE(ctx && desc && h_cs && out, GL_ERR_ARG, "null argument");
+    GL_TRY(validate_desc(*desc));
+    GL_TRY(ctx->activate());
+    std::unique_ptr<gl_circuit, void (*)(gl_circuit*)> c(new gl_circuit(), gl_circuit_free);
+    c->ctx = ctx; c->desc = *desc; c->n = size_t(1) << desc->degree_bits;
+    const size_t n = c->n, ncs = desc->num_constants + 80;
+    std::vector<const uint64_t*> cols(ncs);
+    for (size_t k = 0; k < ncs; k++) cols[k] = h_cs + k * n;
+    GL_TRY(gl_batch_from_values(ctx, cols.data(), ncs, n, desc->rate_bits, 0, desc->cap_height, &c->cs_batch));   // circuit_builder.rs:1020-1028
+    GL_CHECK_HIP(hipMalloc((void**)&c->d_sigmas, 80 * n * sizeof(gl_t)));
+    GL_TRY(gl_copy_h2d(ctx, c->d_sigmas, h_cs + (size_t)desc->num_constants * n, 80 * n * sizeof(gl_t)));
+    // circuit_digest = hash_no_pad(cap || hash_pad([]) || [degree_bits])   (circuit_builder.rs:1089-1100)
+    std::vector<gl_t> parts((size_t(4) << desc->cap_height));
+    GL_TRY(gl_batch_cap(c->cs_batch, parts.data()));
+    gl_t padded[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1}, ds[4];                   // plonk/config.rs:41-51
+    glhost::host_hash_no_pad(padded, 12, ds);
+    for (int k = 0; k < 4; k++) parts.push_back(ds[k]);
+    parts.push_back(desc->degree_bits);
+    glhost::host_hash_no_pad(parts.data(), parts.size(), c->circuit_digest);
+    *out = c.release();
+    return GL_OK;
+}
+extern "C" int gl_circuit_from_host(gl_ctx* ctx, const gl_host_circuit* hc, gl_circuit** out) {
+    GL_REQUIRE(hc, GL_ERR_ARG, "null host circuit");
+    return gl_circuit_create(ctx, &hc->hc.desc, hc->hc.constants_sigmas.data(), out);
+}
+extern "C" int gl_circuit_digest(const gl_circuit* c, uint64_t h_out[4]) {
+    GL_REQUIRE(c && h_out, GL_ERR_ARG, "null argument");
+    memcpy(h_out, c->circuit_digest, 32);
+    return GL_OK;
+}
+extern "C" int gl_circuit_constants_sigmas_cap(const gl_circuit* c, uint64_t* h_out) {
+    GL_REQUIRE(c && h_out, GL_ERR_ARG, "null argument");
+    return gl_batch_cap(c->cs_batch, h_out);
+}
+extern "C" const gl_batch* gl_circuit_constants_sigmas_batch(const gl_circuit* c) { return c ? c->cs_batch : nullptr; }
+
+// ---- helpers -------------------------------------------------------------------------------------------------------------
+static inline gl2_t h_ext(gl_t a, gl_t b) { return gl2_make(a, b); }
+static void put_u64(std::vector<uint8_t>& o, uint64_t v) { for (int i = 0; i < 8; i++) o.push_back((uint8_t)(v >> (8 * i))); }
+static void put_words(std::vector<uint8_t>& o, const gl_t* v, size_t n) { for (size_t i = 0; i < n; i++) put_u64(o, gl_canon(v[i])); }
+static uint32_t host_bitrev32(uint32_t x, uint32_t bits) { uint32_t r = 0; for (uint32_t i = 0; i < bits; i++) r = (r << 1) | ((x >> i) & 1); return r; }
+
+struct DevBuf {                     // RAII device allocation on the ctx's device
+    void* p = nullptr;
+    int alloc(size_t bytes) { GL_CHECK_HIP(hipMalloc(&p, bytes ? bytes : 8)); return GL_OK; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <class T> T* as() const { return (T*)p; }
+};
+struct BatchHolder { gl_batch* b = nullptr; ~BatchHolder() { if (b) gl_batch_free(b); } };
+struct MerkleHolder { GlMerkle m; ~MerkleHolder() { gl_merkle_release(&m); } };
+
+static int d2h(gl_ctx* c, void* dst, const void* src, size_t bytes) { return gl_copy_d2h(c, dst, src, bytes); }
+static int h2d_async(gl_ctx* c, void* dst, const void* src, size_t bytes) {
+    // sources are small host vectors that outlive the next sync; pageable H2D is staged by the runtime before returning
+    GL_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return GL_OK;
+}
+
+extern "C" int gl_prove(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, const uint64_t* h_pis, size_t npis, gl_proof** out) {
+    GL_REQUIRE(ctx && cir && h_wires && h_pis && out, GL_ERR_ARG, "gl_prove: null argument");
+    GL_REQUIRE(cir->ctx == ctx, GL_ERR_ARG, "gl_prove: circuit belongs to another context");
+    const gl_circuit_desc& d = cir->desc;
+    GL_REQUIRE(npis == d.num_public_inputs, GL_ERR_ARG, "gl_prove: wrong number of public inputs");
+    GL_TRY(ctx->activate());
+    const size_t n = cir->n, N = n << d.rate_bits;
+    const uint32_t lgn = d.degree_bits, lgN = lgn + d.rate_bits, ncap = 4u << d.cap_height;
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<gl_proof> proof(new gl_proof());
+
+    // ---- 4. wires commitment (prover.rs:145-156) ----
+    DevBuf d_wit; GL_TRY(d_wit.alloc(135 * n * sizeof(gl_t)));
+    ctx->timing_begin("H2D witness");
+    GL_CHECK_HIP(hipMemcpyAsync(d_wit.p, h_wires, 135 * n * sizeof(gl_t), hipMemcpyHostToDevice, st));
+    ctx->timing_end();
+    BatchHolder wires; GL_TRY(gl_batch_from_device(ctx, d_wit.as<uint64_t>(), 135, n, d.rate_bits, d.cap_height, 1, &wires.b));
+    // public_inputs_hash (prover.rs:126-127) on the host while the GPU commits
+    gl_t pi_hash[4];
+    glhost::host_hash_no_pad(h_pis, npis, pi_hash);
+    HostChallenger ch;
+    ch.observe_many(cir->circuit_digest, 4);
+    ch.observe_many(pi_hash, 4);
+    std::vector<gl_t> cap(ncap);
+    GL_TRY(gl_batch_cap(wires.b, cap.data()));
+    proof->caps.insert(proof->caps.end(), cap.begin(), cap.end());
+    ch.observe_many(cap.data(), ncap);
+    gl_t betas[2], gammas[2], alphas[2];
+    for (int i = 0; i < 2; i++) betas[i] = ch.challenge();
+    for (int i = 0; i < 2; i++) gammas[i] = ch.challenge();
+
+    // ---- 6/7. partial products and Z, commitment (prover.rs:189-223) ----
+    DevBuf d_zs; GL_TRY(d_zs.alloc(20 * n * sizeof(gl_t)));
+    {
+        DevBuf d_chunk, d_rowp, d_seg;
+        const uint32_t nseg = (uint32_t)((n + GLP_SEG - 1) / GLP_SEG);
+        GL_TRY(d_chunk.alloc(2 * GLP_CHUNKS * n * sizeof(gl_t)));
+        GL_TRY(d_rowp.alloc(2 * n * sizeof(gl_t)));
+        GL_TRY(d_seg.alloc(2 * (size_t)nseg * sizeof(gl_t)));
+        GlPowTable xt;
+        GL_TRY(ctx->get_pow_table(gl_host_root_of_unity(lgn), 1, (uint32_t)((n + 2047) >> 11), &xt));
+        GlPermParams pp;
+        pp.wires = d_wit.as<gl_t>(); pp.sigmas = cir->d_sigmas; pp.xpow_lo = xt.lo; pp.xpow_hi = xt.hi;
+        for (int j = 0; j < 80; j++) pp.k_is[j] = d.k_is[j];
+        for (int i = 0; i < 2; i++) { pp.betas[i] = betas[i]; pp.gammas[i] = gammas[i]; }
+        pp.n = (uint32_t)n; pp.chunk_prod = d_chunk.as<gl_t>(); pp.row_prod = d_rowp.as<gl_t>();
+        ctx->timing_begin("compute partial products");
+        hipLaunchKernelGGL(k_pp_chunk_products, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pp);
+        hipLaunchKernelGGL(k_z_segment_products, dim3(nseg, 2), dim3(256), 0, st, d_rowp.as<gl_t>(), (uint32_t)n, d_seg.as<gl_t>());
+        hipLaunchKernelGGL(k_z_segment_scan, dim3(1), dim3(64), 0, st, d_seg.as<gl_t>(), nseg);
+        hipLaunchKernelGGL(k_z_finalize, dim3(nseg, 2), dim3(256), 0, st, d_rowp.as<gl_t>(), d_chunk.as<gl_t>(), d_seg.as<gl_t>(), (uint32_t)n, d_zs.as<gl_t>());
+        ctx->timing_end();
+        GL_CHECK_HIP(hipGetLastError());
+        GL_CHECK_HIP(hipStreamSynchronize(st));       // temporaries are released at scope exit
+    }
+    proof->zs_pp.resize(20 * n);
+    GL_TRY(d2h(ctx, proof->zs_pp.data(), d_zs.p, 20 * n * sizeof(gl_t)));
+    BatchHolder zs; GL_TRY(gl_batch_from_device(ctx, d_zs.as<uint64_t>(), 20, n, d.rate_bits, d.cap_height, 1, &zs.b));
+    GL_TRY(gl_batch_cap(zs.b, cap.data()));
+    proof->caps.insert(proof->caps.end(), cap.begin(), cap.end());
+    ch.observe_many(cap.data(), ncap);
+    for (int i = 0; i < 2; i++) alphas[i] = ch.challenge();
+
+    // ---- 9/10. quotient polynomials (prover.rs:229-271) ----
+    DevBuf d_q; GL_TRY(d_q.alloc(2 * N * sizeof(gl_t)));
+    {
+        std::vector<gl_t> apow(2 * GLQ_MAX_TERMS);
+        for (int b = 0; b < 2; b++) { gl_t x = 1; for (int t = 0; t < GLQ_MAX_TERMS; t++) { apow[b * GLQ_MAX_TERMS + t] = x; x = gl_canon(gl_mul(x, alphas[b])); } }
+        GL_TRY(ctx->ensure_dev_small(1 << 20));
+        gl_t* d_apow = ctx->dev_small;
+        GL_TRY(h2d_async(ctx, d_apow, apow.data(), apow.size() * sizeof(gl_t)));
+        GlPowTable xt;
+        GL_TRY(ctx->get_pow_table(gl_host_root_of_unity(lgN), GL_MULT_GENERATOR, (uint32_t)((N + 2047) >> 11), &xt));
+        GlQuotParams q;
+        ::memset((void*)&q, 0, sizeof q);
+        q.cs = cir->cs_batch->lde; q.wires = wires.b->lde; q.zs = zs.b->lde; q.xpow_lo = xt.lo; q.xpow_hi = xt.hi;
+        q.alpha_pows = d_apow; q.out = d_q.as<gl_t>();
+        for (int j = 0; j < 80; j++) q.k_is[j] = d.k_is[j];
+        for (int i = 0; i < 2; i++) { q.betas[i] = betas[i]; q.gammas[i] = gammas[i]; }
+        for (int i = 0; i < 4; i++) q.pi_hash[i] = pi_hash[i];
+        {   // ZeroPolyOnCoset (field/src/zero_poly_coset.rs:19-36)
+            gl_t g_pow_n = GL_MULT_GENERATOR; for (uint32_t i = 0; i < lgn; i++) g_pow_n = gl_sqr(g_pow_n);
+            gl_t w8 = gl_host_root_of_unity(d.rate_bits), x = 1;
+            for (int i = 0; i < 8; i++) { q.zh_evals[i] = gl_canon(gl_sub(gl_mul(g_pow_n, x), 1)); q.zh_inv[i] = gl_canon(gl_inv(q.zh_evals[i])); x = gl_mul(x, w8); }
+        }
+        q.n_field = (gl_t)n; q.lgN = lgN; q.num_constants = d.num_constants; q.num_selectors = d.num_selectors; q.num_gates = d.num_gates;
+        q.next_step = 1u << d.rate_bits;
+        for (unsigned g = 0; g < d.num_gates; g++) { q.gate_types[g] = d.gate_types[g]; q.gate_sel[g] = d.gate_selector_index[g]; q.group_start[g] = d.gate_group_start[g]; q.group_end[g] = d.gate_group_end[g]; }
+        ctx->timing_begin("compute quotient polys");
+        hipLaunchKernelGGL(k_quotient, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
+        ctx->timing_end();
+        GL_CHECK_HIP(hipGetLastError());
+        // coset_ifft(7) of each quotient (prover.rs:739-743); the 8n coefficients ARE the 8 chunks of n (prover.rs:245-258)
+        GL_TRY(gl_ntt_run(ctx, d_q.as<gl_t>(), N, (uint32_t)N, d_q.as<gl_t>(), N, lgN, 2, true, 0, gl_canon(gl_inv(GL_MULT_GENERATOR)), gl_host_inverse_2exp(lgN)));
+    }
+    proof->quotient.resize(16 * n);
+    GL_TRY(d2h(ctx, proof->quotient.data(), d_q.p, 16 * n * sizeof(gl_t)));
+    BatchHolder quot; GL_TRY(gl_batch_from_device(ctx, d_q.as<uint64_t>(), 16, n, d.rate_bits, d.cap_height, 0, &quot.b));
+    GL_TRY(gl_batch_cap(quot.b, cap.data()));
+    proof->caps.insert(proof->caps.end(), cap.begin(), cap.end());
+    ch.observe_many(cap.data(), ncap);
+
+    // ---- 11. zeta (prover.rs:273-283) ----
+    gl2_t zeta; zeta.a = ch.challenge(); zeta.b = ch.challenge();
+    {
+        gl2_t zn = zeta;
+        for (uint32_t i = 0; i < lgn; i++) zn = gl2_mul(zn, zn);
+        zn = gl2_canon(zn);
+        if (zn.a == 1 && zn.b == 0) return gl_fail(GL_ERR_ZETA_IN_SUBGROUP, "Opening point is in the subgroup.", __FILE__, __LINE__);
+    }
+    const gl_t g = gl_host_root_of_unity(lgn);
+    const gl2_t gzeta = gl2_canon(gl2_scalar(zeta, g));
+
+    // ---- 12. openings (proof.rs:306-344) ----
+    const gl_batch* oracles[4] = {cir->cs_batch, wires.b, zs.b, quot.b};
+    const size_t ncs = d.num_constants + 80, nopen = ncs + 135 + 20 + 16;
+    std::vector<gl_t> open_zeta(2 * nopen), open_next(2 * 2);
+    {
+        GL_TRY(ctx->ensure_dev_small(1 << 20));
+        gl_t* d_open = ctx->dev_small + 4096;
+        size_t off = 0;
+        ctx->timing_begin("construct the opening set");
+        for (int o = 0; o < 4; o++) {
+            hipLaunchKernelGGL(k_eval_at_ext, dim3((unsigned)oracles[o]->ncols), dim3(256), 0, st, oracles[o]->coeffs, (uint32_t)n, (uint64_t)n, zeta.a, zeta.b, d_open + 2 * off);
+            off += oracles[o]->ncols;
+        }
+        hipLaunchKernelGGL(k_eval_at_ext, dim3(2), dim3(256), 0, st, zs.b->coeffs, (uint32_t)n, (uint64_t)n, gzeta.a, gzeta.b, d_open + 2 * nopen);
+        ctx->timing_end();
+        GL_CHECK_HIP(hipGetLastError());
+        std::vector<gl_t> tmp(2 * nopen + 4);
+        GL_TRY(d2h(ctx, tmp.data(), d_open, tmp.size() * sizeof(gl_t)));
+        memcpy(open_zeta.data(), tmp.data(), 2 * nopen * sizeof(gl_t));
+        memcpy(open_next.data(), tmp.data() + 2 * nopen, 4 * sizeof(gl_t));
+    }
+    // FriOpenings order = oracle order: constants, sigmas, wires, zs, partial products, quotient; then zs_next
+    ch.observe_many(open_zeta.data(), open_zeta.size());
+    ch.observe_many(open_next.data(), open_next.size());
+
+    // ---- 14. prove_openings (fri/oracle.rs:162-219) ----
+    gl2_t fri_alpha; fri_alpha.a = ch.challenge(); fri_alpha.b = ch.challenge();
+    DevBuf d_final;    GL_TRY(d_final.alloc(2 * n * sizeof(gl_t)));            // planes a, b of alpha^2 Q0 + Q1
+    {
+        DevBuf d_F, d_heads, d_cols, d_apow;
+        const uint32_t nseg = (uint32_t)((n + GLP_DIV_SEG - 1) / GLP_DIV_SEG);
+        GL_TRY(d_F.alloc(2 * n * sizeof(gl_t)));
+        GL_TRY(d_heads.alloc(2 * (size_t)nseg * sizeof(gl_t)));
+        GL_TRY(d_cols.alloc((nopen + 2) * sizeof(gl_t*)));
+        GL_TRY(d_apow.alloc(2 * (nopen + 2) * sizeof(gl_t)));
+        std::vector<const gl_t*> cols;
+        for (int o = 0; o < 4; o++) for (size_t c = 0; c < oracles[o]->ncols; c++) cols.push_back(oracles[o]->coeffs + c * n);
+        cols.push_back(zs.b->coeffs); cols.push_back(zs.b->coeffs + n);
+        std::vector<gl_t> apow(2 * (nopen + 2));
+        { gl2_t x = gl2_make(1, 0); for (size_t j = 0; j < nopen; j++) { apow[2 * j] = x.a; apow[2 * j + 1] = x.b; x = gl2_canon(gl2_mul(x, fri_alpha)); } }
+        { gl2_t x = gl2_make(1, 0); for (size_t j = 0; j < 2; j++) { apow[2 * (nopen + j)] = x.a; apow[2 * (nopen + j) + 1] = x.b; x = gl2_canon(gl2_mul(x, fri_alpha)); } }
+        GL_TRY(h2d_async(ctx, d_cols.p, cols.data(), cols.size() * sizeof(gl_t*)));
+        GL_TRY(h2d_async(ctx, d_apow.p, apow.data(), apow.size() * sizeof(gl_t)));
+        gl_t* Fa = d_F.as<gl_t>(); gl_t* Fb = Fa + n;
+        gl_t* Qa = d_final.as<gl_t>(); gl_t* Qb = Qa + n;
+        const gl2_t shift = gl2_canon(gl2_mul(fri_alpha, fri_alpha));     // alpha^(#polys of batch 1) (reducing.rs:103-106)
+        const unsigned gb = (unsigned)((n + 255) / 256), sb = (nseg + 63) / 64;
+        ctx->timing_begin("reduce batch + divide by linear");
+        // batch 0: all polynomials at zeta
+        hipLaunchKernelGGL(k_fri_combine, dim3(gb), dim3(256), 0, st, d_cols.as<const gl_t*>(), d_apow.as<gl_t>(), (uint32_t)nopen, (uint32_t)n, Fa, Fb);
+        hipLaunchKernelGGL(k_div_linear_heads, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, zeta.a, zeta.b, d_heads.as<gl_t>());
+        hipLaunchKernelGGL(k_div_linear_carries, dim3(1), dim3(64), 0, st, d_heads.as<gl_t>(), (uint32_t)n, zeta.a, zeta.b);
+        hipLaunchKernelGGL(k_div_linear_apply, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, zeta.a, zeta.b, d_heads.as<gl_t>(), shift.a, shift.b, Qa, Qb, 0);
+        // batch 1: the Z polynomials at g * zeta
+        hipLaunchKernelGGL(k_fri_combine, dim3(gb), dim3(256), 0, st, d_cols.as<const gl_t*>() + nopen, d_apow.as<gl_t>() + 2 * nopen, 2u, (uint32_t)n, Fa, Fb);
+        hipLaunchKernelGGL(k_div_linear_heads, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, gzeta.a, gzeta.b, d_heads.as<gl_t>());
+        hipLaunchKernelGGL(k_div_linear_carries, dim3(1), dim3(64), 0, st, d_heads.as<gl_t>(), (uint32_t)n, gzeta.a, gzeta.b);
+        hipLaunchKernelGGL(k_div_linear_apply, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, gzeta.a, gzeta.b, d_heads.as<gl_t>(), (gl_t)1, (gl_t)0, Qa, Qb, 1);
+        ctx->timing_end();
+        GL_CHECK_HIP(hipGetLastError());
+        GL_CHECK_HIP(hipStreamSynchronize(st));
+    }
+    // final_poly.lde(rate_bits).coset_fft(7) on both planes (fri/oracle.rs:199-204)
+    DevBuf d_vals; GL_TRY(d_vals.alloc(2 * N * sizeof(gl_t)));
+    GL_TRY(gl_ntt_run(ctx, d_final.as<gl_t>(), n, (uint32_t)n, d_vals.as<gl_t>(), N, lgN, 2, false, GL_MULT_GENERATOR, 0, 1));
+
+    // ---- fri_committed_trees (fri/prover.rs:69-112) ----
+    std::vector<std::unique_ptr<MerkleHolder>> fri_trees;
+    std::vector<std::unique_ptr<DevBuf>> fri_vals;          // value planes of each round (kept for the query phase)
+    std::vector<uint32_t> fri_lg;                           // log2 of each round's value length
+    std::vector<gl_t> fri_caps, fri_betas;
+    std::unique_ptr<DevBuf> cur_vals(new DevBuf());
+    cur_vals->p = d_vals.p; d_vals.p = nullptr;
+    DevBuf coef_a, coef_b;                                  // ping-pong coefficient planes [2][cur_n]
+    coef_a.p = d_final.p; d_final.p = nullptr;
+    size_t cur_n = n;                                       // non-zero coefficients
+    uint32_t cur_lgN = lgN;
+    gl_t shift = GL_MULT_GENERATOR;
+    for (unsigned r = 0; r < d.num_fri_rounds; r++) {
+        const uint32_t ab = d.fri_arity_bits[r], arity = 1u << ab;
+        const size_t curN = size_t(1) << cur_lgN;
+        // leaves: `arity` consecutive entries of the bit-reversed value array, flattened (fri/prover.rs:80-89)
+        std::vector<uint64_t> offs(2 * arity);
+        for (uint32_t k = 0; k < arity; k++)
+            for (uint32_t cpt = 0; cpt < 2; cpt++) offs[2 * k + cpt] = (uint64_t)cpt * curN + (uint64_t)host_bitrev32(k, ab) * (curN >> ab);
+        std::unique_ptr<MerkleHolder> tree(new MerkleHolder());
+        GL_TRY(gl_merkle_build(ctx, cur_vals->as<gl_t>(), offs.data(), 2 * arity, cur_lgN - ab, d.cap_height, &tree->m));
+        GL_TRY(d2h(ctx, cap.data(), tree->m.level_ptr(tree->m.num_levels() - 1), ncap * sizeof(gl_t)));
+        fri_caps.insert(fri_caps.end(), cap.begin(), cap.end());
+        ch.observe_many(cap.data(), ncap);
+        gl2_t beta; beta.a = ch.challenge(); beta.b = ch.challenge();
+        fri_betas.push_back(beta.a); fri_betas.push_back(beta.b);
+        // fold the coefficients (fri/prover.rs:94-103)
+        const size_t next_n = cur_n >> ab;
+        GL_REQUIRE(next_n >= 1, GL_ERR_INTERNAL, "FRI fold below one coefficient");
+        GL_TRY(coef_b.alloc(2 * next_n * sizeof(gl_t)));
+        ctx->timing_begin("fold codewords in the commitment phase");
+        hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((next_n + 255) / 256)), dim3(256), 0, st, coef_a.as<gl_t>(), coef_a.as<gl_t>() + cur_n,
+                           (uint32_t)next_n, arity, beta.a, beta.b, coef_b.as<gl_t>(), coef_b.as<gl_t>() + next_n);
+        ctx->timing_end();
+        GL_CHECK_HIP(hipGetLastError());
+        shift = gl_canon(gl_exp(shift, arity));
+        fri_trees.push_back(std::move(tree)); fri_vals.push_back(std::move(cur_vals)); fri_lg.push_back(cur_lgN);
+        cur_lgN -= ab;
+        cur_vals.reset(new DevBuf());
+        GL_TRY(cur_vals->alloc(2 * (size_t(1) << cur_lgN) * sizeof(gl_t)));
+        GL_TRY(gl_ntt_run(ctx, coef_b.as<gl_t>(), next_n, (uint32_t)next_n, cur_vals->as<gl_t>(), size_t(1) << cur_lgN, cur_lgN, 2, false, shift, 0, 1));
+        GL_CHECK_HIP(hipStreamSynchronize(st));
+        std::swap(coef_a.p, coef_b.p);
+        (void)hipFree(coef_b.p); coef_b.p = nullptr;
+        cur_n = next_n;
+    }
+    // final polynomial: the remaining non-zero coefficients (coeffs.truncate(len >> rate_bits), fri/prover.rs:106-111)
+    std::vector<gl_t> fin_il(2 * cur_n);
+    {
+        std::vector<gl_t> fin(2 * cur_n);
+        GL_TRY(d2h(ctx, fin.data(), coef_a.p, 2 * cur_n * sizeof(gl_t)));
+        for (size_t i = 0; i < cur_n; i++) { fin_il[2 * i] = fin[i]; fin_il[2 * i + 1] = fin[cur_n + i]; }
+    }
+    ch.observe_many(fin_il.data(), fin_il.size());
+
+    // ---- fri_proof_of_work (fri/prover.rs:115-160): smallest valid witness ----
+    gl_t pow_witness = 0;
+    {
+        GL_TRY(ctx->ensure_dev_small(1 << 20));
+        unsigned long long* d_res = (unsigned long long*)ctx->dev_small;
+        GlPowParams pw;
+        for (int i = 0; i < 12; i++) pw.state[i] = ch.state[i];
+        for (int i = 0; i < ch.nin; i++) pw.state[i] = ch.in[i];
+        pw.pos = (uint32_t)ch.nin; pw.min_leading_zeros = d.proof_of_work_bits; pw.result = d_res;
+        const uint64_t batch = uint64_t(1) << 20;
+        unsigned long long res = ~0ull;
+        ctx->timing_begin("find proof-of-work witness");
+        for (uint64_t base = 0; base < GL_P; base += batch) {
+            GL_CHECK_HIP(hipMemsetAsync(d_res, 0xFF, sizeof(unsigned long long), st));
+            pw.base = base; pw.count = (GL_P - base < batch) ? GL_P - base : batch;
+            hipLaunchKernelGGL(k_pow_grind, dim3((unsigned)((pw.count + 255) / 256)), dim3(256), 0, st, pw);
+            GL_CHECK_HIP(hipGetLastError());
+            GL_TRY(d2h(ctx, &res, d_res, sizeof res));
+            if (res != ~0ull) break;
+        }
+        ctx->timing_end();
+        GL_REQUIRE(res != ~0ull, GL_ERR_INTERNAL, "Proof of work failed. This is highly unlikely!");
+        pow_witness = (gl_t)res;
+    }
+    ch.observe(pow_witness);
+    const gl_t pow_response = ch.challenge();
+    GL_REQUIRE(pow_response == 0 || (uint32_t)__builtin_clzll(pow_response) >= d.proof_of_work_bits, GL_ERR_INTERNAL, "PoW response mismatch");
+
+    // ---- query rounds (fri/prover.rs:162-216) ----
+    const uint32_t nq = d.num_query_rounds;
+    std::vector<uint32_t> x_index(nq);
+    for (uint32_t q = 0; q < nq; q++) { x_index[q] = (uint32_t)(ch.challenge() % (uint64_t)N); proof->query_indices.push_back(x_index[q]); }
+    // staging layout (u64 words): per oracle: rows [nq][ncols], paths [nq][levels][4]; per FRI round: leaves [nq][arity][2], paths
+    struct Piece { size_t off, words; };
+    std::vector<Piece> row_piece(4), path_piece(4), fleaf_piece(d.num_fri_rounds), fpath_piece(d.num_fri_rounds);
+    size_t total = 0;
+    const uint32_t init_levels = lgN - d.cap_height;
+    for (int o = 0; o < 4; o++) {
+        row_piece[o] = {total, nq * oracles[o]->ncols}; total += row_piece[o].words;
+        path_piece[o] = {total, (size_t)nq * init_levels * 4}; total += path_piece[o].words;
+    }
+    for (unsigned r = 0; r < d.num_fri_rounds; r++) {
+        const uint32_t ab = d.fri_arity_bits[r], lv = fri_lg[r] - ab - d.cap_height;
+        fleaf_piece[r] = {total, (size_t)nq * (2u << ab)}; total += fleaf_piece[r].words;
+        fpath_piece[r] = {total, (size_t)nq * lv * 4}; total += fpath_piece[r].words;
+    }
+    DevBuf d_stage, d_idx;
+    GL_TRY(d_stage.alloc((total + 8) * sizeof(gl_t)));
+    GL_TRY(d_idx.alloc((size_t)nq * (2 + d.num_fri_rounds) * sizeof(uint32_t)));
+    std::vector<uint32_t> idx_host((size_t)nq * (2 + d.num_fri_rounds));
+    for (uint32_t q = 0; q < nq; q++) { idx_host[q] = x_index[q]; idx_host[nq + q] = host_bitrev32(x_index[q], lgN); }
+    {
+        std::vector<uint32_t> xi(x_index);
+        for (unsigned r = 0; r < d.num_fri_rounds; r++) for (uint32_t q = 0; q < nq; q++) { xi[q] >>= d.fri_arity_bits[r]; idx_host[(size_t)(2 + r) * nq + q] = xi[q]; }
+    }
+    GL_TRY(h2d_async(ctx, d_idx.p, idx_host.data(), idx_host.size() * sizeof(uint32_t)));
+    const uint32_t* d_leaf = d_idx.as<uint32_t>();            // Merkle leaf indices
+    const uint32_t* d_rows = d_leaf + nq;                     // natural LDE rows = bitrev(leaf)
+    gl_t* stage = d_stage.as<gl_t>();
+    ctx->timing_begin("FRI query gathers");
+    for (int o = 0; o < 4; o++) {
+        const gl_batch* b = oracles[o];
+        const uint64_t* d_lo = nullptr;
+        GL_TRY(ctx->get_offsets_table(b->tree.level_off.data(), b->tree.level_off.size(), &d_lo));
+        unsigned cnt = nq * (unsigned)b->ncols;
+        hipLaunchKernelGGL(k_gather_rows, dim3((cnt + 255) / 256), dim3(256), 0, st, b->lde, (uint64_t)N, (uint32_t)b->ncols, d_rows, nq, stage + row_piece[o].off);
+        cnt = nq * init_levels * 4;
+        if (cnt) hipLaunchKernelGGL(k_gather_paths, dim3((cnt + 255) / 256), dim3(256), 0, st, b->tree.digests, d_lo, init_levels, d_leaf, nq, stage + path_piece[o].off);
+    }
+    for (unsigned r = 0; r < d.num_fri_rounds; r++) {
+        const uint32_t ab = d.fri_arity_bits[r], lv = fri_lg[r] - ab - d.cap_height;
+        const GlMerkle& t = fri_trees[r]->m;
+        const uint64_t* d_lo = nullptr;
+        GL_TRY(ctx->get_offsets_table(t.level_off.data(), t.level_off.size(), &d_lo));
+        const gl_t* va = fri_vals[r]->as<gl_t>(); const gl_t* vb = va + (size_t(1) << fri_lg[r]);
+        const uint32_t* d_fl = d_idx.as<uint32_t>() + (size_t)(2 + r) * nq;
+        unsigned cnt = nq << ab;
+        hipLaunchKernelGGL(k_gather_fri_leaves, dim3((cnt + 255) / 256), dim3(256), 0, st, va, vb, fri_lg[r], ab, d_fl, nq, stage + fleaf_piece[r].off);
+        cnt = nq * lv * 4;
+        if (cnt) hipLaunchKernelGGL(k_gather_paths, dim3((cnt + 255) / 256), dim3(256), 0, st, t.digests, d_lo, lv, d_fl, nq, stage + fpath_piece[r].off);
+    }
+    ctx->timing_end();
+    GL_CHECK_HIP(hipGetLastError());
+    std::vector<gl_t> host_stage(total + 8);
+    GL_TRY(d2h(ctx, host_stage.data(), stage, total * sizeof(gl_t)));
+
+    // ---- 15. assemble ProofWithPublicInputs bytes (util/serialization/mod.rs:1939-1981) ----
+    std::vector<uint8_t>& o = proof->bytes;
+    o.reserve(300000);
+    put_words(o, proof->caps.data(), proof->caps.size());                        // wires_cap, zs_pp_cap, quotient_cap
+    // OpeningSet (:1409-1423): constants, sigmas, wires, zs, zs_next, [lookups: empty], partial products, quotient
+    {
+        const gl_t* z = open_zeta.data();
+        size_t o_cs = 0, o_w = 2 * ncs, o_z = o_w + 2 * 135, o_pp = o_z + 2 * 2, o_q = o_z + 2 * 20;
+        put_words(o, z + o_cs, 2 * ncs);
+        put_words(o, z + o_w, 2 * 135);
+        put_words(o, z + o_z, 2 * 2);
+        put_words(o, open_next.data(), 2 * 2);
+        put_words(o, z + o_pp, 2 * 18);
+        put_words(o, z + o_q, 2 * 16);
+    }
+    put_words(o, fri_caps.data(), fri_caps.size());
+    for (uint32_t q = 0; q < nq; q++) {
+        for (int oi = 0; oi < 4; oi++) {
+            const size_t nc = oracles[oi]->ncols;
+            put_words(o, host_stage.data() + row_piece[oi].off + (size_t)q * nc, nc);
+            o.push_back((uint8_t)init_levels);
+            put_words(o, host_stage.data() + path_piece[oi].off + (size_t)q * init_levels * 4, (size_t)init_levels * 4);
+        }
+        for (unsigned r = 0; r < d.num_fri_rounds; r++) {
+            const uint32_t ab = d.fri_arity_bits[r], lv = fri_lg[r] - ab - d.cap_height;
+            put_words(o, host_stage.data() + fleaf_piece[r].off + (size_t)q * (2u << ab), 2u << ab);
+            o.push_back((uint8_t)lv);
+            put_words(o, host_stage.data() + fpath_piece[r].off + (size_t)q * lv * 4, (size_t)lv * 4);
+        }
+    }
+    put_words(o, fin_il.data(), fin_il.size());
+    put_u64(o, pow_witness);
+    put_u64(o, npis);
+    put_words(o, h_pis, npis);
+
+    std::vector<gl_t>& cv = proof->challenges;
+    for (int i = 0; i < 2; i++) cv.push_back(betas[i]);
+    for (int i = 0; i < 2; i++) cv.push_back(gammas[i]);
+    for (int i = 0; i < 2; i++) cv.push_back(alphas[i]);
+    cv.push_back(zeta.a); cv.push_back(zeta.b); cv.push_back(fri_alpha.a); cv.push_back(fri_alpha.b); cv.push_back(pow_witness);
+    for (int i = 0; i < 4; i++) cv.push_back(pi_hash[i]);
+    cv.insert(cv.end(), fri_betas.begin(), fri_betas.end());
+    GL_CHECK_HIP(hipStreamSynchronize(st));
+    *out = proof.release();
+    return GL_OK;
+}
+
+extern "C" size_t gl_proof_num_bytes(const gl_proof* p) { return p ? p->bytes.size() : 0; }
+extern "C" int gl_proof_bytes(const gl_proof* p, uint8_t* h_out, size_t cap) {
+    GL_REQUIRE(p && h_out && cap >= p->bytes.size(), GL_ERR_ARG, "buffer too small");
+    memcpy(h_out, p->bytes.data(), p->bytes.size());
+    return GL_OK;
+}
+extern "C" size_t gl_proof_challenges(const gl_proof* p, uint64_t* h_out) {
+    if (!p || !h_out) return 0;
+    memcpy(h_out, p->challenges.data(), p->challenges.size() * sizeof(gl_t));
+    return p->challenges.size();
+}
+extern "C" int gl_proof_caps(const gl_proof* p, uint64_t* h_out) {
+    GL_REQUIRE(p && h_out, GL_ERR_ARG, "null argument");
+    memcpy(h_out, p->caps.data(), p->caps.size() * sizeof(gl_t));
+    return GL_OK;
+}
+extern "C" int gl_proof_zs_partial_products(const gl_proof* p, uint64_t* h_out) {
+    GL_REQUIRE(p && h_out, GL_ERR_ARG, "null argument");
+    memcpy(h_out, p->zs_pp.data(), p->zs_pp.size() * sizeof(gl_t));
+    return GL_OK;
+}
+extern "C" int gl_proof_quotient_chunks(const gl_proof* p, uint64_t* h_out) {
+    GL_REQUIRE(p && h_out, GL_ERR_ARG, "null argument");
+    memcpy(h_out, p->quotient.data(), p->quotient.size() * sizeof(gl_t));
+    return GL_OK;
+}
+extern "C" size_t gl_proof_query_indices(const gl_proof* p, uint64_t* h_out) {
+    if (!p || !h_out) return 0;
+    memcpy(h_out, p->query_indices.data(), p->query_indices.size() * sizeof(uint64_t));
+    return p->query_indices.size();
+}
+extern "C" void gl_proof_free(gl_proof* p) { delete p; }

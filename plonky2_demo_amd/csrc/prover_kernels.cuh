@@ -1,0 +1,450 @@
+// Device kernels for the prove() phases between the polynomial commitments.
+//   k_pp_chunk_products / k_z_*      permutation argument: quotient chunk products, running product Z and partial
+//                                    products   (plonk/prover.rs:359-416, util/partial_products.rs:13-37)
+//   k_quotient                       vanishing-polynomial evaluation on the LDE coset, x 1/Z_H
+//                                    (plonk/prover.rs:576-737, plonk/vanishing_poly.rs:164-330, gates/*.rs)
+//   k_eval_at_ext                    OpeningSet::new: p(zeta) for every committed polynomial (plonk/proof.rs:306-344)
+//   k_fri_combine / k_div_linear_*   prove_openings: sum_j alpha^j f_j and (F - F(z))/(X - z)
+//                                    (fri/oracle.rs:162-219, util/reducing.rs:83-106, polynomial/division.rs:75-88)
+//   k_fri_fold                       commit-phase coefficient fold (fri/prover.rs:94-103)
+//   k_pow_grind                      proof of work (fri/prover.rs:115-160), minimum witness
+//   k_gather_*                       query answers (fri/prover.rs:162-216)
+// All values are exact field elements; every reordering used here (per-gate alpha sums, forward alpha powers,
+// chunk-level inversion, segmented scans) is an identity in F_p / F_p^2, so results equal the reference's.
+// Data layout: column-major "structure of polynomials" ([poly][index]); extension polynomials as two planes.
+#pragma once
+#include "gl64.cuh"
+#include "poseidon.cuh"
+#include "../../include/plonky2_mi355x.h"
+
+#define GLP_MAX_ROUTED 80
+#define GLP_CHUNKS 10           // ceil(80 / 8)
+
+struct GlPermParams {
+    const gl_t* wires;          // witness VALUES [num_wires][n]
+    const gl_t* sigmas;         // sigma VALUES [80][n]
+    const gl_t* xpow_lo; const gl_t* xpow_hi;   // two-level table of w_n^i
+    gl_t k_is[GLP_MAX_ROUTED];
+    gl_t betas[2], gammas[2];
+    uint32_t n;
+    gl_t* chunk_prod;           // [2][10][n]
+    gl_t* row_prod;             // [2][n]
+};
+
+__device__ __forceinline__ gl_t glp_pow2level(const gl_t* lo, const gl_t* hi, uint32_t e) {
+    return gl_mul(lo[e & 2047], hi[e >> 11]);
+}
+
+// one thread per trace row: the 10 chunk products  prod_{j in chunk} (w_j + beta k_j x + gamma) / (w_j + beta sigma_j + gamma)
+__global__ __launch_bounds__(256) void k_pp_chunk_products(GlPermParams p) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    const gl_t x = glp_pow2level(p.xpow_lo, p.xpow_hi, i);
+#pragma unroll 1
+    for (int a = 0; a < 2; a++) {
+        const gl_t beta = p.betas[a], gamma = p.gammas[a];
+        const gl_t bx = gl_mul(beta, x);
+        gl_t nump[GLP_CHUNKS], denp[GLP_CHUNKS];
+#pragma unroll
+        for (int c = 0; c < GLP_CHUNKS; c++) {
+            gl_t np = 1, dp = 1;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int j = c * 8 + q;
+                const gl_t w = p.wires[(size_t)j * p.n + i];
+                const gl_t s = p.sigmas[(size_t)j * p.n + i];
+                np = gl_mul(np, gl_add(gl_mul_add(w, bx, p.k_is[j]), gamma));
+                dp = gl_mul(dp, gl_add(gl_mul_add(w, beta, s), gamma));
+            }
+            nump[c] = np; denp[c] = dp;
+        }
+        // invert the 10 denominators with one inversion (Montgomery)
+        gl_t pre[GLP_CHUNKS];
+        gl_t acc = 1;
+#pragma unroll
+        for (int c = 0; c < GLP_CHUNKS; c++) { pre[c] = acc; acc = gl_mul(acc, denp[c]); }
+        gl_t inv = gl_inv(acc);
+        gl_t rowp = 1;
+#pragma unroll
+        for (int c = GLP_CHUNKS - 1; c >= 0; c--) {
+            gl_t dinv = gl_mul(inv, pre[c]);
+            inv = gl_mul(inv, denp[c]);
+            nump[c] = gl_mul(nump[c], dinv);
+        }
+#pragma unroll
+        for (int c = 0; c < GLP_CHUNKS; c++) {
+            p.chunk_prod[((size_t)a * GLP_CHUNKS + c) * p.n + i] = gl_canon(nump[c]);
+            rowp = gl_mul(rowp, nump[c]);
+        }
+        p.row_prod[(size_t)a * p.n + i] = gl_canon(rowp);
+    }
+}
+
+// ---- exclusive multiplicative scan of row_prod over rows: Z(x_i) = prod_{i' < i} P_i' -----------------------
+#define GLP_SEG 2048            // rows per workgroup segment (256 threads x 8)
+
+// S1: product of each segment
+__global__ __launch_bounds__(256) void k_z_segment_products(const gl_t* row_prod, uint32_t n, gl_t* seg_prod) {
+    __shared__ gl_t sh[256];
+    const uint32_t a = blockIdx.y, seg = blockIdx.x, t = threadIdx.x;
+    const gl_t* rp = row_prod + (size_t)a * n;
+    gl_t acc = 1;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { uint32_t i = seg * GLP_SEG + t * 8 + q; if (i < n) acc = gl_mul(acc, rp[i]); }
+    sh[t] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) sh[t] = gl_mul(sh[t], sh[t + s]); __syncthreads(); }
+    if (t == 0) seg_prod[(size_t)a * gridDim.x + seg] = gl_canon(sh[0]);
+}
+// S2: exclusive scan of the segment products (one thread per challenge; segment counts are tiny)
+__global__ void k_z_segment_scan(gl_t* seg_prod, uint32_t nseg) {
+    const uint32_t a = threadIdx.x;
+    if (a >= 2) return;
+    gl_t acc = 1;
+    for (uint32_t s = 0; s < nseg; s++) { gl_t v = seg_prod[(size_t)a * nseg + s]; seg_prod[(size_t)a * nseg + s] = acc; acc = gl_canon(gl_mul(acc, v)); }
+}
+// S3: per-row Z and the nine partial products.  out columns: [Z_0, Z_1, pp_0[0..9), pp_1[0..9)], each n values
+__global__ __launch_bounds__(256) void k_z_finalize(const gl_t* row_prod, const gl_t* chunk_prod, const gl_t* seg_excl, uint32_t n, gl_t* out) {
+    __shared__ gl_t sh[256];
+    const uint32_t a = blockIdx.y, seg = blockIdx.x, t = threadIdx.x, nseg = gridDim.x;
+    const gl_t* rp = row_prod + (size_t)a * n;
+    gl_t loc[8];
+    gl_t acc = 1;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { uint32_t i = seg * GLP_SEG + t * 8 + q; loc[q] = acc; if (i < n) acc = gl_mul(acc, rp[i]); }
+    sh[t] = acc;
+    __syncthreads();
+    // exclusive scan of the 256 per-thread products (Hillis-Steele on inclusive values)
+    for (int d = 1; d < 256; d <<= 1) {
+        gl_t v = (t >= (uint32_t)d) ? sh[t - d] : 1;
+        __syncthreads();
+        sh[t] = gl_mul(sh[t], v);
+        __syncthreads();
+    }
+    gl_t prefix = gl_mul(seg_excl[(size_t)a * nseg + seg], t ? sh[t - 1] : 1);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        uint32_t i = seg * GLP_SEG + t * 8 + q;
+        if (i >= n) break;
+        gl_t z = gl_mul(prefix, loc[q]);
+        out[(size_t)a * n + i] = gl_canon(z);                                     // Z_a(x_i)
+        gl_t run = z;
+#pragma unroll
+        for (int c = 0; c < GLP_CHUNKS - 1; c++) {
+            run = gl_mul(run, chunk_prod[((size_t)a * GLP_CHUNKS + c) * n + i]);
+            out[(size_t)(2 + a * (GLP_CHUNKS - 1) + c) * n + i] = gl_canon(run);  // partial product c of challenge a
+        }
+    }
+}
+
+// ---- quotient ------------------------------------------------------------------------------------------------
+struct GlQuotParams {
+    const gl_t* cs;             // constants||sigmas LDE [num_constants + 80][N] natural order
+    const gl_t* wires;          // wires LDE [135][N]
+    const gl_t* zs;             // Z||partial products LDE [20][N]
+    const gl_t* xpow_lo; const gl_t* xpow_hi;    // 7 * w_N^i two-level
+    const gl_t* alpha_pows;     // [2][152]: alpha_b^t
+    gl_t* out;                  // [2][N]
+    gl_t k_is[GLP_MAX_ROUTED];
+    gl_t betas[2], gammas[2];
+    gl_t pi_hash[4];
+    gl_t zh_evals[8], zh_inv[8];    // Z_H on the coset by i mod 8 and inverses (field/src/zero_poly_coset.rs)
+    gl_t n_field;                   // n as a field element
+    uint32_t lgN, num_constants, num_selectors, num_gates, next_step;
+    uint8_t gate_types[8];
+    uint32_t gate_sel[8], group_start[8], group_end[8];
+};
+#define GLQ_MAX_TERMS 152
+
+// running alpha-weighted sums for the two alphas
+struct GlAlphaAcc {
+    gl_t s0, s1;
+    const gl_t* ap;             // alpha_pows base
+    __device__ __forceinline__ void add(uint32_t t, gl_t term) {
+        s0 = gl_mul_add(s0, term, ap[t]);
+        s1 = gl_mul_add(s1, term, ap[GLQ_MAX_TERMS + t]);
+    }
+};
+
+// PoseidonGate constraints (gates/poseidon.rs:193-272), term index base `t0`, streamed wire reads
+__device__ __forceinline__ void glq_poseidon_gate(const gl_t* __restrict__ w, size_t N, GlAlphaAcc& acc, uint32_t t0) {
+    uint32_t t = t0;
+    const gl_t swap = w[24 * N];
+    acc.add(t++, gl_mul(swap, gl_sub(swap, 1)));
+    gl_t s[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const gl_t lhs = w[(size_t)i * N], rhs = w[(size_t)(i + 4) * N], delta = w[(size_t)(25 + i) * N];
+        acc.add(t++, gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), delta));
+        s[i] = gl_add(lhs, delta);
+        s[i + 4] = gl_sub(rhs, delta);
+    }
+#pragma unroll
+    for (int i = 8; i < 12; i++) s[i] = w[(size_t)i * N];
+    int round = 0;
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl_add_c(s[i], d_POSEIDON_RC[12 * round + i]);
+        if (r != 0) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) { const gl_t in = w[(size_t)(29 + 12 * (r - 1) + i) * N]; acc.add(t++, gl_sub(s[i], in)); s[i] = in; }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = psd_sbox(s[i]);
+        psd_mds(s);
+        round++;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add_c(s[i], d_POSEIDON_PARTIAL_FIRST_RC[i]);
+    {
+        gl_t tmp[12];
+        tmp[0] = s[0];
+#pragma unroll
+        for (int c = 1; c < 12; c++) {
+            gl_t a2 = 0;
+#pragma unroll
+            for (int r = 1; r < 12; r++) a2 = gl_mul_add(a2, s[r], d_POSEIDON_PARTIAL_INIT[(r - 1) * 11 + (c - 1)]);
+            tmp[c] = a2;
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = tmp[i];
+    }
+#pragma unroll 1
+    for (int r = 0; r < POSEIDON_PARTIAL_ROUNDS; r++) {
+        const gl_t in = w[(size_t)(65 + r) * N];
+        acc.add(t++, gl_sub(s[0], in));
+        const gl_t s0 = gl_add_c(psd_sbox(in), d_POSEIDON_PARTIAL_RC[r]);
+        gl_t dd = gl_mul_small(s0, 25);
+#pragma unroll
+        for (int i = 1; i < 12; i++) dd = gl_mul_add(dd, s[i], d_POSEIDON_PARTIAL_ROW[r * 11 + i - 1]);
+#pragma unroll
+        for (int i = 1; i < 12; i++) s[i] = gl_mul_add(s[i], s0, d_POSEIDON_PARTIAL_COL[r * 11 + i - 1]);
+        s[0] = dd;
+    }
+    round += POSEIDON_PARTIAL_ROUNDS;
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl_add_c(s[i], d_POSEIDON_RC[12 * round + i]);
+#pragma unroll
+        for (int i = 0; i < 12; i++) { const gl_t in = w[(size_t)(87 + 12 * r + i) * N]; acc.add(t++, gl_sub(s[i], in)); s[i] = in; }
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = psd_sbox(s[i]);
+        psd_mds(s);
+        round++;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) acc.add(t++, gl_sub(s[i], w[(size_t)(12 + i) * N]));
+}
+
+__global__ __launch_bounds__(256) void k_quotient(GlQuotParams p) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t N = size_t(1) << p.lgN;
+    if (i >= N) return;
+    const gl_t x = glp_pow2level(p.xpow_lo, p.xpow_hi, i);          // 7 * w^i
+    const gl_t* w = p.wires + i;
+    const gl_t* cs = p.cs + i;
+    const gl_t* zs = p.zs + i;
+    const uint32_t i_next = (i + p.next_step) & (uint32_t)(N - 1);
+    GlAlphaAcc total; total.s0 = 0; total.s1 = 0; total.ap = p.alpha_pows;
+    // L_0(x) (Z(x) - 1)            (vanishing_poly.rs:263-268; zero_poly_coset.rs:55-60)
+    const gl_t l0 = gl_mul(p.zh_evals[i & 7], gl_inv(gl_mul(p.n_field, gl_sub(x, 1))));
+    total.add(0, gl_mul(l0, gl_sub(zs[0], 1)));
+    total.add(1, gl_mul(l0, gl_sub(zs[N], 1)));
+    // partial-product checks (util/partial_products.rs:52-76): terms 2 + 10 a + c
+    {
+        gl_t bx0 = gl_mul(p.betas[0], x), bx1 = gl_mul(p.betas[1], x);
+        gl_t prev0 = zs[0], prev1 = zs[N];
+#pragma unroll 1
+        for (int c = 0; c < GLP_CHUNKS; c++) {
+            gl_t n0 = 1, d0 = 1, n1 = 1, d1 = 1;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int j = c * 8 + q;
+                const gl_t wv = w[(size_t)j * N], sg = cs[(size_t)(p.num_constants + j) * N], k = p.k_is[j];
+                n0 = gl_mul(n0, gl_add(gl_mul_add(wv, bx0, k), p.gammas[0]));
+                d0 = gl_mul(d0, gl_add(gl_mul_add(wv, p.betas[0], sg), p.gammas[0]));
+                n1 = gl_mul(n1, gl_add(gl_mul_add(wv, bx1, k), p.gammas[1]));
+                d1 = gl_mul(d1, gl_add(gl_mul_add(wv, p.betas[1], sg), p.gammas[1]));
+            }
+            const gl_t next0 = (c == GLP_CHUNKS - 1) ? p.zs[i_next] : zs[(size_t)(2 + c) * N];
+            const gl_t next1 = (c == GLP_CHUNKS - 1) ? p.zs[N + i_next] : zs[(size_t)(2 + (GLP_CHUNKS - 1) + c) * N];
+            total.add(2 + c, gl_sub(gl_mul(prev0, n0), gl_mul(next0, d0)));
+            total.add(2 + GLP_CHUNKS + c, gl_sub(gl_mul(prev1, n1), gl_mul(next1, d1)));
+            prev0 = next0; prev1 = next1;
+        }
+    }
+    // gate constraints: sum_g filter_g * sum_j alpha^(22+j) c_{g,j}   (vanishing_poly.rs:706-732, gate.rs:121-146)
+    const uint32_t T0 = 2 + 2 * GLP_CHUNKS;
+    const gl_t* gc = cs + (size_t)p.num_selectors * N;              // the gate's own constants
+#pragma unroll 1
+    for (uint32_t g = 0; g < p.num_gates; g++) {
+        const gl_t sel = cs[(size_t)p.gate_sel[g] * N];
+        gl_t filter = 1;                                            // gate.rs:277-284
+        for (uint32_t k = p.group_start[g]; k < p.group_end[g]; k++) if (k != g) filter = gl_mul(filter, gl_sub((gl_t)k, sel));
+        if (p.num_selectors > 1) filter = gl_mul(filter, gl_sub((gl_t)0xFFFFFFFFull, sel));
+        GlAlphaAcc acc; acc.s0 = 0; acc.s1 = 0; acc.ap = p.alpha_pows;
+        switch (p.gate_types[g]) {
+            case 1:     // ConstantGate (gates/constant.rs:59-66)
+                acc.add(T0, gl_sub(gc[0], w[0]));
+                acc.add(T0 + 1, gl_sub(gc[N], w[N]));
+                break;
+            case 2:     // PublicInputGate (gates/public_input.rs:44-49)
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc.add(T0 + k, gl_sub(w[(size_t)k * N], p.pi_hash[k]));
+                break;
+            case 3: {   // ArithmeticGate (gates/arithmetic_base.rs:163-181)
+                const gl_t c0 = gc[0], c1 = gc[N];
+#pragma unroll 4
+                for (int k = 0; k < 20; k++) {
+                    const gl_t m0 = w[(size_t)(4 * k) * N], m1 = w[(size_t)(4 * k + 1) * N], ad = w[(size_t)(4 * k + 2) * N], o = w[(size_t)(4 * k + 3) * N];
+                    const gl_t computed = gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(ad, c1));
+                    acc.add(T0 + k, gl_sub(o, computed));
+                }
+                break;
+            }
+            case 4: glq_poseidon_gate(w, N, acc, T0); break;
+            default: break;   // NoopGate
+        }
+        total.s0 = gl_mul_add(total.s0, filter, acc.s0);
+        total.s1 = gl_mul_add(total.s1, filter, acc.s1);
+    }
+    const gl_t zi = p.zh_inv[i & 7];
+    p.out[i] = gl_canon(gl_mul(total.s0, zi));
+    p.out[N + i] = gl_canon(gl_mul(total.s1, zi));
+}
+
+// ---- openings: p(z) in F_p^2 for `npolys` base polynomials of n coefficients ---------------------------------------
+// grid = (npolys); block = 256: thread t does Horner over its strip, strips are combined with z^(strip start)
+__global__ __launch_bounds__(256) void k_eval_at_ext(const gl_t* coeffs, uint32_t n, uint64_t stride, gl_t za, gl_t zb, gl_t* out /* [npolys][2] */) {
+    __shared__ gl_t sha[256], shb[256];
+    const uint32_t poly = blockIdx.x, t = threadIdx.x;
+    const gl_t* c = coeffs + (uint64_t)poly * stride;
+    const gl2_t z = gl2_make(za, zb);
+    const uint32_t strip = (n + 255) / 256;
+    const uint32_t lo = t * strip, hi = (lo + strip < n) ? lo + strip : n;
+    gl2_t acc = gl2_make(0, 0);
+    for (uint32_t k = hi; k > lo; k--) {
+        acc = gl2_mul(acc, z);
+        acc.a = gl_add(acc.a, c[k - 1]);
+    }
+    if (lo < n) acc = gl2_mul(acc, gl2_exp(z, lo)); else acc = gl2_make(0, 0);
+    sha[t] = acc.a; shb[t] = acc.b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < (uint32_t)s) { sha[t] = gl_add(sha[t], sha[t + s]); shb[t] = gl_add(shb[t], shb[t + s]); }
+        __syncthreads();
+    }
+    if (t == 0) { out[2 * poly] = gl_canon(sha[0]); out[2 * poly + 1] = gl_canon(shb[0]); }
+}
+
+// ---- FRI: F = sum_j alpha^j f_j over a list of coefficient columns --------------------------------------------------
+// cols: device array of npolys pointers; apow: [npolys][2]; out planes a[n], b[n] (accumulate = add into existing)
+__global__ __launch_bounds__(256) void k_fri_combine(const gl_t* const* cols, const gl_t* apow, uint32_t npolys, uint32_t n, gl_t* out_a, gl_t* out_b) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gl_t a = 0, b = 0;
+    for (uint32_t j = 0; j < npolys; j++) {
+        const gl_t c = cols[j][i];
+        a = gl_mul_add(a, c, apow[2 * j]);
+        b = gl_mul_add(b, c, apow[2 * j + 1]);
+    }
+    out_a[i] = gl_canon(a); out_b[i] = gl_canon(b);
+}
+
+// (F(X) - F(z)) / (X - z) by segmented backward Horner: b_i = b_{i+1} z + c_i, quotient[i] = b_{i+1}, quotient[n-1] = 0
+#define GLP_DIV_SEG 64
+// D1: head value of each segment assuming zero carry-in:  L_s = sum_{k in seg} c_k z^(k - start)
+__global__ void k_div_linear_heads(const gl_t* ca, const gl_t* cb, uint32_t n, gl_t za, gl_t zb, gl_t* heads /* [nseg][2] */) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, nseg = (n + GLP_DIV_SEG - 1) / GLP_DIV_SEG;
+    if (s >= nseg) return;
+    const gl2_t z = gl2_make(za, zb);
+    const uint32_t lo = s * GLP_DIV_SEG, hi = (lo + GLP_DIV_SEG < n) ? lo + GLP_DIV_SEG : n;
+    gl2_t acc = gl2_make(0, 0);
+    for (uint32_t k = hi; k > lo; k--) acc = gl2_add(gl2_mul(acc, z), gl2_make(ca[k - 1], cb[k - 1]));
+    heads[2 * s] = acc.a; heads[2 * s + 1] = acc.b;
+}
+// D2: carries B_s = b at the start of segment s: B_s = L_s + z^len(s) * B_{s+1}; stores carry-in of each segment
+__global__ void k_div_linear_carries(gl_t* heads, uint32_t n, gl_t za, gl_t zb) {
+    if (threadIdx.x || blockIdx.x) return;
+    const uint32_t nseg = (n + GLP_DIV_SEG - 1) / GLP_DIV_SEG;
+    const gl2_t z = gl2_make(za, zb);
+    const gl2_t zseg = gl2_exp(z, GLP_DIV_SEG);
+    gl2_t carry = gl2_make(0, 0);                    // b_n = 0
+    for (uint32_t s = nseg; s-- > 0;) {
+        const uint32_t lo = s * GLP_DIV_SEG, len = (lo + GLP_DIV_SEG < n) ? GLP_DIV_SEG : n - lo;
+        gl2_t head = gl2_make(heads[2 * s], heads[2 * s + 1]);
+        heads[2 * s] = carry.a; heads[2 * s + 1] = carry.b;                 // carry-in for segment s
+        carry = gl2_add(head, gl2_mul(len == GLP_DIV_SEG ? zseg : gl2_exp(z, len), carry));
+    }
+}
+// D3: exact recurrence inside each segment, writing the quotient; result = scale * quotient (+ addend if given)
+__global__ void k_div_linear_apply(const gl_t* ca, const gl_t* cb, uint32_t n, gl_t za, gl_t zb, const gl_t* carries,
+                                   gl_t sa, gl_t sb, gl_t* qa, gl_t* qb, int accumulate) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, nseg = (n + GLP_DIV_SEG - 1) / GLP_DIV_SEG;
+    if (s >= nseg) return;
+    const gl2_t z = gl2_make(za, zb), scale = gl2_make(sa, sb);
+    const uint32_t lo = s * GLP_DIV_SEG, hi = (lo + GLP_DIV_SEG < n) ? lo + GLP_DIV_SEG : n;
+    gl2_t b = gl2_make(carries[2 * s], carries[2 * s + 1]);          // b_hi
+    for (uint32_t k = hi; k > lo; k--) {
+        // quotient[k-1] = b_k
+        gl2_t q = gl2_mul(b, scale);
+        if (accumulate) q = gl2_add(q, gl2_make(qa[k - 1], qb[k - 1]));
+        qa[k - 1] = gl_canon(q.a); qb[k - 1] = gl_canon(q.b);
+        b = gl2_add(gl2_mul(b, z), gl2_make(ca[k - 1], cb[k - 1]));
+    }
+}
+
+// ---- FRI fold: out[k] = sum_{i < arity} beta^i in[arity k + i]   (fri/prover.rs:94-103, plonk_common.rs:116-128) ------
+__global__ __launch_bounds__(256) void k_fri_fold(const gl_t* ia, const gl_t* ib, uint32_t n_out, uint32_t arity, gl_t ba, gl_t bb, gl_t* oa, gl_t* ob) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_out) return;
+    const gl2_t beta = gl2_make(ba, bb);
+    gl2_t acc = gl2_make(0, 0);
+    for (uint32_t i = arity; i-- > 0;) acc = gl2_add(gl2_mul(acc, beta), gl2_make(ia[(size_t)arity * k + i], ib[(size_t)arity * k + i]));
+    oa[k] = gl_canon(acc.a); ob[k] = gl_canon(acc.b);
+}
+
+// ---- proof of work: smallest w >= base with clz(permute(state with w at pos)[7]) >= bits ----------------------------------
+struct GlPowParams { gl_t state[12]; uint32_t pos, min_leading_zeros; uint64_t base, count; unsigned long long* result; };
+__global__ __launch_bounds__(256) void k_pow_grind(GlPowParams p) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.count) return;
+    const uint64_t cand = p.base + idx;
+    gl_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = p.state[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) if ((uint32_t)i == p.pos) s[i] = cand;
+    psd_permute(s);
+    const gl_t r = gl_canon(s[7]);
+    const uint32_t lz = r ? (uint32_t)__clzll((long long)r) : 64u;
+    if (lz >= p.min_leading_zeros) atomicMin(p.result, (unsigned long long)cand);
+}
+
+// ---- gathers for the query phase -----------------------------------------------------------------------------------------
+// rows of a column-major matrix: out[q][c] = base[c * stride + rows[q]]
+__global__ void k_gather_rows(const gl_t* base, uint64_t stride, uint32_t ncols, const uint32_t* rows, uint32_t nq, gl_t* out) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nq * ncols) return;
+    const uint32_t q = idx / ncols, c = idx % ncols;
+    out[idx] = base[(uint64_t)c * stride + rows[q]];
+}
+// Merkle paths: out[q][l][4] = digests[level_off[l] + ((leaf[q] >> l) ^ 1)]
+__global__ void k_gather_paths(const gl_t* digests, const uint64_t* level_off, uint32_t nlevels, const uint32_t* leaves, uint32_t nq, gl_t* out) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nq * nlevels * 4) return;
+    const uint32_t k = idx & 3, l = (idx >> 2) % nlevels, q = (idx >> 2) / nlevels;
+    out[idx] = digests[4 * (level_off[l] + ((leaves[q] >> l) ^ 1u)) + k];
+}
+// FRI step leaves: leaf j of a tree over an ext SoA array = positions bitrev(arity*j + k): out[q][k][2]
+__global__ void k_gather_fri_leaves(const gl_t* va, const gl_t* vb, uint32_t lg_len, uint32_t arity_bits, const uint32_t* leaves, uint32_t nq, gl_t* out) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t arity = 1u << arity_bits;
+    if (idx >= nq * arity) return;
+    const uint32_t q = idx >> arity_bits, k = idx & (arity - 1);
+    const uint32_t pos = (leaves[q] << arity_bits) | k;                       // index in the bit-reversed array
+    const uint32_t nat = lg_len ? (__brev(pos) >> (32 - lg_len)) : 0;         // natural-order index
+    out[2 * idx] = va[nat]; out[2 * idx + 1] = vb[nat];
+}

@@ -42,3 +42,25 @@ def test_no_gpu_fails_loudly():
     import plonky2_demo_amd as p
     with pytest.raises(p.Plonky2Mi355xError):
         p.Context(0)
+
+
+# ---- host-side circuit builder of the product (no GPU) against the oracle's independent restatement ----------
+@pytest.mark.parametrize("m", [1, 2, 3, 5, 8, 20])
+def test_host_matmul_circuit_matches_oracle(orc, m):
+    import numpy as np
+    import plonky2_demo_amd as p
+    from oracle_lib import rand_field
+    hc = p.MatmulCircuit(m)
+    oc = orc.circuit(m, threads=4)
+    assert hc.degree_bits == oc.info["degree_bits"]
+    assert hc.desc.num_constants == oc.info["num_constants"] and hc.desc.num_selectors == oc.info["num_selectors"]
+    assert hc.desc.num_fri_rounds == oc.info["num_fri_rounds"] and hc.desc.num_public_inputs == oc.info["num_public_inputs"]
+    assert list(hc.desc.gate_types[: hc.desc.num_gates]) == oc.gate_order()
+    assert (hc.row_gates() == oc.row_gates()).all()
+    # constants + the 80 sigma polynomials: two independent constructions (closed-form classes vs union-find forest)
+    assert (hc.constants_sigmas() == oc.constants_sigmas()).all()
+    a, b = rand_field(m, m * m) % (2**32 - 1), rand_field(m + 100, m * m) % (2**32 - 1)
+    wires, pis = hc.witness(a, b, filler_seed=99)
+    ow = oc.witness(a, b, filler_seed=99)
+    assert (pis == ow.public_inputs()).all()
+    assert (wires == ow.wires()).all()

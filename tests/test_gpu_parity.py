@@ -219,3 +219,54 @@ def test_polynomial_batch_matches_oracle(gpu, orc, ncols, lg, rate, cap):
             assert (lde[:, rev] == leaf).all()
             assert (gb.get_lde_values(rev, 1) == leaf).all()      # oracle.rs:128-133
         gb.free()
+
+
+# ---------------------------------------------------------------------------------------------------- prove()
+def _prove_both(p, orc, m, seed, threads=8):
+    hc = p.MatmulCircuit(m)
+    oc = orc.circuit(m, threads=threads)
+    a, b = rand_field(seed, m * m) % (2**32 - 1), rand_field(seed + 1, m * m) % (2**32 - 1)
+    wires, pis = hc.witness(a, b, filler_seed=seed)
+    cd = hc.build()
+    assert (cd.constants_sigmas_cap == oc.constants_sigmas_cap).all()
+    assert (cd.circuit_digest == oc.digest).all()
+    gp = cd.prove(wires, pis)
+    op = oc.witness(a, b, filler_seed=seed).prove(threads=threads)
+    return gp, op
+
+
+@pytest.mark.parametrize("m", [2, 3, 8, 20])
+def test_prove_is_byte_identical_to_the_oracle(gpu, orc, m):
+    # BASELINE configs[0] (m = 2, README instance shape) and sizes with 0, 1 and 2 FRI reduction rounds
+    p, ctx = gpu
+    gp, op = _prove_both(p, orc, m, 1000 + m)
+    assert gp.challenges() == op.challenges()
+    assert (gp.caps() == op.caps()).all()
+    assert (gp.zs_partial_products() == op.zs_partial_products()).all()
+    assert (gp.quotient_chunks() == op.quotient_chunks()).all()
+    assert gp.query_indices() == op.query_indices()
+    assert gp.to_bytes() == op.to_bytes()
+    assert op.verify()[0]                      # ... and the native verifier restatement accepts those bytes' proof
+
+
+def test_prove_readme_instance(gpu, orc):
+    p, ctx = gpu
+    hc = p.MatmulCircuit(2)
+    wires, pis = hc.witness([1, 2, 3, 4], [5, 6, 7, 8])
+    assert pis.reshape(-1, 3)[:, 2].tolist() == [19, 22, 43, 50]
+    proof = hc.build().prove(wires, pis)
+    op = orc.circuit(2).witness([1, 2, 3, 4], [5, 6, 7, 8]).prove()
+    assert proof.to_bytes() == op.to_bytes() and len(proof.to_bytes()) == 70288
+    with pytest.raises(p.Plonky2Mi355xError):
+        hc.build().prove(wires, pis[:-1])      # wrong number of public inputs
+
+
+def test_prove_m64_matches_oracle(gpu, orc):
+    # BASELINE configs[2]: m = 64, n = 2^15, three arity-16 FRI rounds; ~250 KB proof
+    p, ctx = gpu
+    gp, op = _prove_both(p, orc, 64, 64, threads=16)
+    assert gp.challenges() == op.challenges()
+    assert (gp.caps() == op.caps()).all()
+    gb = gp.to_bytes()
+    assert gb == op.to_bytes() and len(gb) == 250756
+    assert op.verify()[0]
