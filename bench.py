@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
-"""Headline benchmark (BASELINE.json configs[1]): 2^20-point Goldilocks forward + inverse NTT on MI355X.
+"""Headline benchmark on MI355X: proofs/sec for the m=64 matmul circuit (full prove()), plus the 2^20 NTT leg.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU; the NTT path shards by polynomial with no
-   data-path collective -> weak scaling, each rank transforms its own batch.)
+  (N > 1: launched by torch.distributed.run, one rank per GPU.  Proofs are independent: rank r proves its own
+   random-witness proofs with replicated circuit data and no data-path collective; the only collective is one
+   RCCL all_gather of the Merkle caps of the proved batch at the end of the timed region -> weak scaling.)
 
-A "step" is one pass of the hot path over one batch of synthetic input resident in HBM: an in-place forward
-NTT of B polynomials of length 2^20 (fft_with_options, field/src/fft.rs:56-65) followed by the inverse
-(ifft_with_options, :72-95).  value = GF elements transformed per second, whole job:
-    world * K * 2 * B * 2^20 / t.
-Prints ONE JSON line on rank 0, including
-  roofline:     forward NTT, algorithmic bytes 16*L*B (one 8-B read + one 8-B write per element)
-                over the measured device time of its two launches (HIP events on the launch stream);
-  cpu_baseline: the CPU restatement of the reference algorithm (oracle/, kind "port") on a bounded sample.
+A "step" is one pass of the hot path over one unit of synthetic input resident in HBM: one prove()
+(plonky2/src/plonk/prover.rs:102-329 from the full witness matrix on: 3 PolynomialBatch commitments, permutation
+argument, quotient, openings, FRI) of the m = 64 circuit (n = 2^15 rows, 135 wire columns, 250 756-byte proof).
+value = whole-job proofs per second = world * K / t.  Witness generation is excluded, the witness matrix is
+already on the device when the clock starts.
+
+The same JSON line carries
+  roofline:     BASELINE configs[1], the HBM-bound kernel family of the path: forward 2^20-point NTT over 64 polynomials,
+                algorithmic bytes 16*L*B (one 8-B read + one 8-B write per element) over the device time of
+                its launches (HIP events on the launch stream);
+  ntt:          GF elements/s of forward+inverse 2^20 NTTs (the second half of BASELINE.json's metric);
+  cpu_baseline: the CPU restatement of the reference prover (oracle/, kind "port") proving the same circuit on the
+                host cores (one proof, bounded).
 """
 import argparse
 import ctypes
@@ -25,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LOG_N = 20
+M = 64
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -37,45 +44,80 @@ def synth_field(torch, shape, seed, device):
     return (hi << 32) | lo
 
 
-def cpu_baseline(batch_cpu):
-    """TEST/BASELINE ONLY: times the oracle's radix-2 FFT (restating field/src/fft.rs) on host cores."""
+def cpu_baseline(m):
+    """BASELINE ONLY: times the oracle's prove() (C++ restatement of plonk/prover.rs) on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
     import oracle_lib
     orc = oracle_lib.load()
     cores = os.cpu_count() or 1
-    x = oracle_lib.rand_field(5, (batch_cpu, 1 << LOG_N))
-    p = x.ctypes.data_as(ctypes.c_void_p)
-    n, b = ctypes.c_size_t(1 << LOG_N), ctypes.c_size_t(batch_cpu)
-    orc.lib.orc_fft_mt(p, n, ctypes.c_size_t(min(batch_cpu, cores)), 0, ctypes.c_uint(cores))   # warm-up, partial
-    x0 = x.copy()
+    threads = min(cores, 64)
+    oc = orc.circuit(m, threads=threads)
+    a = oracle_lib.rand_field(64, m * m) % (2**32 - 1)
+    b = oracle_lib.rand_field(65, m * m) % (2**32 - 1)
+    w = oc.witness(a, b)
     t0 = time.perf_counter()
-    orc.lib.orc_fft_mt(p, n, b, 0, ctypes.c_uint(cores))
-    orc.lib.orc_fft_mt(p, n, b, 1, ctypes.c_uint(cores))
+    proof = w.prove(threads=threads)
     dt = time.perf_counter() - t0
-    # only the first min(batch, cores) polynomials went through the warm-up transform first
-    ok = bool((x[cores:] == x0[cores:]).all()) if batch_cpu > cores else True
+    ok = proof.verify()[0]
     return {
-        "value": 2.0 * batch_cpu * (1 << LOG_N) / dt,
-        "unit": "GF-elems/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": "%d polynomials of 2^20, forward+inverse, C++ restatement of field/src/fft.rs, %d threads over "
-                  "polynomials (as oracle.rs:54 par_iter), %.2f s wall%s" % (batch_cpu, cores, dt, "" if ok else " (ROUND TRIP FAILED)"),
+        "value": 1.0 / dt, "unit": "proofs/s", "cores": threads, "kind": "port",
+        "sample": "1 proof of the m=%d circuit by the C++ restatement of the reference prover (oracle/gl_prover.hpp), %d threads over "
+                  "columns / LDE points as the reference's Rayon axes, %.2f s wall, verifier restatement %s" % (m, threads, dt, "accepts" if ok else "REJECTS"),
     }
+
+
+def ntt_leg(torch, ctx, lib, check, dev, batch):
+    L = 1 << LOG_N
+    data = synth_field(torch, (batch, L), 20, dev)
+    ref = data.clone()
+    ptr = ctypes.c_void_p(data.data_ptr())
+    for _ in range(2):
+        check(lib.gl_ntt_forward(ctx.handle, ptr, LOG_N, batch)); check(lib.gl_ntt_inverse(ctx.handle, ptr, LOG_N, batch))
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        check(lib.gl_ntt_forward(ctx.handle, ptr, LOG_N, batch)); check(lib.gl_ntt_inverse(ctx.handle, ptr, LOG_N, batch))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    intact = bool(torch.equal(data, ref))
+    ctx.timing(True)
+    for _ in range(reps):
+        check(lib.gl_ntt_forward(ctx.handle, ptr, LOG_N, batch))
+    rep = ctx.timing_report()
+    ctx.timing(False)
+    fwd_ms = sum(v["ms"] for v in rep.values()) / reps
+    launches = {k: {"per_ntt": v["count"] / reps, "avg_ms": round(v["ms"] / v["count"], 5)} for k, v in rep.items()}
+    algo = 16.0 * L * batch
+    achieved = algo / (fwd_ms * 1e-3) / 1e9
+    traffic = None
+    tr_path = os.path.join(ROOT, "profiles", "ntt20_traffic.json")
+    if os.path.exists(tr_path):
+        try:
+            traffic = json.load(open(tr_path)).get("forward_ntt_hbm_bytes")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel": "forward 2^20 NTT x %d polynomials = ntt_col_pass<10> + ntt_row_pass<10>" % batch,
+                "algorithmic_bytes": algo, "launches": launches}
+    ntt = {"metric": "Goldilocks NTT GF-elems/sec at 2^20 (forward+inverse)", "value": reps * 2.0 * batch * L / dt, "unit": "GF-elems/s",
+           "batch": batch, "round_trip_bit_exact": intact}
+    del data, ref
+    return roofline, ntt
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="polynomials of 2^20 per GPU (64 -> 512 MiB, beyond the 256 MiB Infinity Cache)")
-    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--m", type=int, default=M)
+    ap.add_argument("--witnesses", type=int, default=4, help="distinct random witnesses cycled through")
+    ap.add_argument("--ntt-batch", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--scratch-log", type=int, default=0, help="log2 of the inter-pass scratch in elements (0 = library default)")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -90,68 +132,62 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from plonky2_demo_amd import Context
+    import plonky2_demo_amd as p
     from plonky2_demo_amd._lib import check, lib
 
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = Context(device=local_rank, stream=stream)
-    if args.scratch_log:
-        ctx.set_scratch_elems(1 << args.scratch_log)
-    B, L = args.batch, 1 << LOG_N
-    data = synth_field(torch, (B, L), 20 + rank, dev)
-    ref = data.clone()
-    ptr = ctypes.c_void_p(data.data_ptr())
+    ctx = p.Context(device=local_rank, stream=stream)
+    m = args.m
+    hc = p.MatmulCircuit(m)
+    cd = hc.build(ctx)                                    # circuit data replicated on every GPU
+    wit = []
+    for k in range(args.witnesses):
+        rng = np.random.default_rng(1000 * rank + k)        # u32 entries as matrix_mul.rs:76-78
+        a = rng.integers(0, 2**32 - 1, m * m, dtype=np.uint64)
+        b = rng.integers(0, 2**32 - 1, m * m, dtype=np.uint64)
+        wires, pis = hc.witness(a, b, filler_seed=1000 * rank + k)
+        t = torch.from_numpy(wires.view(np.int64)).to(dev)  # witness matrix resident in HBM
+        wit.append((t, pis))
 
-    def step():
-        check(lib.gl_ntt_forward(ctx.handle, ptr, LOG_N, B))
-        check(lib.gl_ntt_inverse(ctx.handle, ptr, LOG_N, B))
+    def step(i):
+        t, pis = wit[i % len(wit)]
+        return cd.prove_device(ctypes.c_void_p(t.data_ptr()), pis)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     barrier()
+    caps = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        caps.append(step(i).caps())
+    if world > 1:                                           # the Merkle-cap gather: 3 x 16 x 32 B per proof
+        mine = torch.from_numpy(np.stack(caps).view(np.int64)).to(dev)
+        allcaps = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allcaps, mine)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    # forward followed by inverse is the identity: the timed work must have left the input bit-identical
-    intact = bool(torch.equal(data, ref))
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
 
-    # per-launch device time of the forward transform (HIP events on the launch stream)
-    ctx.timing(True)
-    reps = 5
-    for _ in range(reps):
-        check(lib.gl_ntt_forward(ctx.handle, ptr, LOG_N, B))
-        check(lib.gl_ntt_inverse(ctx.handle, ptr, LOG_N, B))
-    rep = ctx.timing_report()
-    ctx.timing(False)
-    kern = {k: v["ms"] / v["count"] for k, v in rep.items()}
-    launches_per_ntt = {k: v["count"] / reps for k, v in rep.items()}
-    fwd_ms = sum(kern[k] * launches_per_ntt[k] for k in kern if "forward" in k)
-    algo_bytes = 16.0 * L * B
-    achieved = algo_bytes / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
-    traffic = None
-    tr_path = os.path.join(ROOT, "profiles", "ntt20_traffic.json")
-    if os.path.exists(tr_path):
-        try:
-            traffic = json.load(open(tr_path)).get("forward_ntt_hbm_bytes_per_launch_pair")
-        except Exception:
-            traffic = None
-
+    proof_bytes = len(step(0).to_bytes())
+    roofline, ntt = (None, None)
     if rank == 0:
+        roofline, ntt = ntt_leg(torch, ctx, lib, check, dev, args.ntt_batch)
+        ctx.timing(True)
+        step(0)
+        scopes = {k: round(v["ms"], 4) for k, v in ctx.timing_report().items()}
+        ctx.timing(False)
         out = {
-            "metric": "Goldilocks NTT GF-elems/sec at 2^20 (forward+inverse)",
-            "value": world * args.steps * 2.0 * B * L / dt,
-            "unit": "GF-elems/s",
+            "metric": "proofs/sec for m=64 matmul circuit (full prove(), PoseidonGoldilocksConfig, standard_recursion_config)",
+            "value": world * args.steps / dt,
+            "unit": "proofs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -161,24 +197,17 @@ def main():
             "vs_baseline": None,
             "dtype": "u64 (Goldilocks, 64-bit modular integer)",
             "data": "synthetic",
-            "config": {"workload": "ntt_2^20_forward+inverse", "log_n": LOG_N, "batch_per_gpu": B,
-                       "bytes_per_gpu": 8 * B * L, "round_trip_bit_exact": intact,
-                       "parallelism": "independent polynomials per GPU, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "forward NTT = ntt_col_pass<10> + ntt_row_pass<10> (two launches)",
-                         "algorithmic_bytes": algo_bytes,
-                         "launch_ms": {k: round(v, 5) for k, v in kern.items()}},
+            "config": {"workload": "prove_matmul_m%d" % m, "trace_rows": hc.n, "lde_size": hc.n << 3, "proof_bytes": proof_bytes,
+                       "witnesses_per_gpu": len(wit), "parallelism": "independent proofs per GPU; RCCL all_gather of Merkle caps only"},
+            "roofline": roofline,
+            "ntt": ntt,
+            "prove_device_ms_by_scope": scopes,
         }
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu_baseline(m) if (world == 1 and not args.no_cpu) else None
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
-    if not intact:
-        raise SystemExit("round trip mismatch: forward+inverse NTT did not restore the input")
 
 
 if __name__ == "__main__":

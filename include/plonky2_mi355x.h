@@ -198,6 +198,9 @@ void gl_circuit_free(gl_circuit* c);
  * Returns GL_ERR_ZETA_IN_SUBGROUP for prover.rs:280-283. */
 int gl_prove(gl_ctx* ctx, const gl_circuit* c, const uint64_t* h_wires, const uint64_t* h_public_inputs,
              size_t num_public_inputs, gl_proof** out);
+/* same with the witness matrix already resident in HBM (d_wires[num_wires][n]) */
+int gl_prove_device(gl_ctx* ctx, const gl_circuit* c, const uint64_t* d_wires, const uint64_t* h_public_inputs,
+                    size_t num_public_inputs, gl_proof** out);
 /* ProofWithPublicInputs::to_bytes (plonk/proof.rs:104-110; util/serialization/mod.rs:1939-1981) */
 size_t gl_proof_num_bytes(const gl_proof* p);
 int gl_proof_bytes(const gl_proof* p, uint8_t* h_out, size_t cap);

@@ -92,6 +92,7 @@ SIGNATURES = {
     "gl_circuit_constants_sigmas_batch": (c_vp, [c_vp]),
     "gl_circuit_free": (None, [c_vp]),
     "gl_prove": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "gl_prove_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "gl_proof_num_bytes": (c_sz, [c_vp]),
     "gl_proof_bytes": (c_int, [c_vp, c_vp, c_sz]),
     "gl_proof_challenges": (c_sz, [c_vp, c_vp]),

@@ -432,6 +432,13 @@ class CircuitData:
         check(lib.gl_prove(self.ctx.handle, self.handle, _p(wires), _p(pis), pis.size, ctypes.byref(h)))
         return Proof(h.value, self.host.n)
 
+    def prove_device(self, d_wires_ptr, public_inputs):
+        """prove() with the witness matrix already in HBM (raw device pointer to [135][n] u64)."""
+        pis = _u64(public_inputs)
+        h = ctypes.c_void_p()
+        check(lib.gl_prove_device(self.ctx.handle, self.handle, d_wires_ptr, _p(pis), pis.size, ctypes.byref(h)))
+        return Proof(h.value, self.host.n)
+
     def __del__(self):
         try:
             if self.handle:

@@ -12,11 +12,19 @@
 
 static int batch_commit(gl_ctx* c, gl_batch* b, bool is_values) {
     // values -> coefficients (oracle.rs:51-55), in place on the device copy
-    if (is_values) GL_TRY(gl_ntt_run(c, b->coeffs, b->n, (uint32_t)b->n, b->coeffs, b->n, b->degree_log, (uint32_t)b->ncols,
-                                     true, 0, 0, gl_host_inverse_2exp(b->degree_log)));
+    if (is_values) {
+        c->timing_begin("IFFT");
+        int st = gl_ntt_run(c, b->coeffs, b->n, (uint32_t)b->n, b->coeffs, b->n, b->degree_log, (uint32_t)b->ncols,
+                            true, 0, 0, gl_host_inverse_2exp(b->degree_log));
+        c->timing_end();
+        GL_TRY(st);
+    }
     // zero-pad x 2^rate_bits and evaluate on the coset 7*H (oracle.rs:100-125)
-    GL_TRY(gl_ntt_run(c, b->coeffs, b->n, (uint32_t)b->n, b->lde, b->N(), b->degree_log + b->rate_bits, (uint32_t)b->ncols,
-                      false, GL_MULT_GENERATOR, 0, 1));
+    c->timing_begin("FFT + blinding");
+    int st_lde = gl_ntt_run(c, b->coeffs, b->n, (uint32_t)b->n, b->lde, b->N(), b->degree_log + b->rate_bits, (uint32_t)b->ncols,
+                            false, GL_MULT_GENERATOR, 0, 1);
+    c->timing_end();
+    GL_TRY(st_lde);
     std::vector<uint64_t> offs(b->ncols);
     for (size_t e = 0; e < b->ncols; e++) offs[e] = e * b->N();
     GL_TRY(gl_merkle_build(c, b->lde, offs.data(), (uint32_t)b->ncols, b->degree_log + b->rate_bits, b->cap_height, &b->tree));

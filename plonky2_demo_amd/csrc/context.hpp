@@ -64,6 +64,7 @@ struct gl_ctx {
     struct TimingRec { const char* name; hipEvent_t start, stop; };
     bool timing_enabled = false;
     std::vector<TimingRec> timing_recs;
+    std::vector<size_t> timing_stack;       // open scopes (scopes nest like the reference's TimingTree)
     void timing_begin(const char* name);
     void timing_end();
 

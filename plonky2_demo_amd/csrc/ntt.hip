@@ -68,11 +68,13 @@ void gl_ctx::timing_begin(const char* name) {
     TimingRec r; r.name = name;
     if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
     (void)hipEventRecord(r.start, stream);
+    timing_stack.push_back(timing_recs.size());
     timing_recs.push_back(r);
 }
 void gl_ctx::timing_end() {
-    if (!timing_enabled || timing_recs.empty()) return;
-    (void)hipEventRecord(timing_recs.back().stop, stream);
+    if (!timing_enabled || timing_stack.empty()) return;
+    (void)hipEventRecord(timing_recs[timing_stack.back()].stop, stream);
+    timing_stack.pop_back();
 }
 struct GlTimed {
     gl_ctx* c;
@@ -91,6 +93,7 @@ extern "C" int gl_ctx_timing_reset(gl_ctx* c) {
     GL_CHECK_HIP(hipStreamSynchronize(c->stream));
     for (auto& r : c->timing_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     c->timing_recs.clear();
+    c->timing_stack.clear();
     return GL_OK;
 }
 // writes a JSON object {"scope": {"count": n, "ms": total}, ...} into buf (NUL-terminated)

@@ -161,7 +161,14 @@ static int h2d_async(gl_ctx* c, void* dst, const void* src, size_t bytes) {
     return GL_OK;
 }
 
+static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, bool wires_on_device, const uint64_t* h_pis, size_t npis, gl_proof** out);
 extern "C" int gl_prove(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, const uint64_t* h_pis, size_t npis, gl_proof** out) {
+    return prove_impl(ctx, cir, h_wires, false, h_pis, npis, out);
+}
+extern "C" int gl_prove_device(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t* h_pis, size_t npis, gl_proof** out) {
+    return prove_impl(ctx, cir, d_wires, true, h_pis, npis, out);
+}
+static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, bool wires_on_device, const uint64_t* h_pis, size_t npis, gl_proof** out) {
     GL_REQUIRE(ctx && cir && h_wires && h_pis && out, GL_ERR_ARG, "gl_prove: null argument");
     GL_REQUIRE(cir->ctx == ctx, GL_ERR_ARG, "gl_prove: circuit belongs to another context");
     const gl_circuit_desc& d = cir->desc;
@@ -175,7 +182,7 @@ extern "C" int gl_prove(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wi
     // ---- 4. wires commitment (prover.rs:145-156) ----
     DevBuf d_wit; GL_TRY(d_wit.alloc(135 * n * sizeof(gl_t)));
     ctx->timing_begin("H2D witness");
-    GL_CHECK_HIP(hipMemcpyAsync(d_wit.p, h_wires, 135 * n * sizeof(gl_t), hipMemcpyHostToDevice, st));
+    GL_CHECK_HIP(hipMemcpyAsync(d_wit.p, h_wires, 135 * n * sizeof(gl_t), wires_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     ctx->timing_end();
     BatchHolder wires; GL_TRY(gl_batch_from_device(ctx, d_wit.as<uint64_t>(), 135, n, d.rate_bits, d.cap_height, 1, &wires.b));
     // public_inputs_hash (prover.rs:126-127) on the host while the GPU commits
