@@ -170,7 +170,8 @@ extern "C" int gl_prove_device(gl_ctx* ctx, const gl_circuit* cir, const uint64_
 }
 static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, bool wires_on_device, const uint64_t* h_pis, size_t npis, gl_proof** out) {
     GL_REQUIRE(ctx && cir && h_wires && h_pis && out, GL_ERR_ARG, "gl_prove: null argument");
-    GL_REQUIRE(cir->ctx == ctx, GL_ERR_ARG, "gl_prove: circuit belongs to another context");
+    // circuit data is read-only while proving: any context (stream) of the same device may prove against it
+    GL_REQUIRE(cir->ctx->device == ctx->device, GL_ERR_ARG, "gl_prove: circuit lives on another device");
     const gl_circuit_desc& d = cir->desc;
     GL_REQUIRE(npis == d.num_public_inputs, GL_ERR_ARG, "gl_prove: wrong number of public inputs");
     GL_TRY(ctx->activate());
@@ -311,7 +312,8 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     DevBuf d_final;    GL_TRY(d_final.alloc(2 * n * sizeof(gl_t)));            // planes a, b of alpha^2 Q0 + Q1
     {
         DevBuf d_F, d_heads, d_cols, d_apow;
-        const uint32_t nseg = (uint32_t)((n + GLP_DIV_SEG - 1) / GLP_DIV_SEG);
+        const uint32_t seg_len = (uint32_t)(n / 1024 > 32 ? n / 1024 : (n >= 32 ? 32 : n));      // at most 1024 segments
+        const uint32_t nseg = (uint32_t)((n + seg_len - 1) / seg_len);
         GL_TRY(d_F.alloc(2 * n * sizeof(gl_t)));
         GL_TRY(d_heads.alloc(2 * (size_t)nseg * sizeof(gl_t)));
         GL_TRY(d_cols.alloc((nopen + 2) * sizeof(gl_t*)));
@@ -331,14 +333,14 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
         ctx->timing_begin("reduce batch + divide by linear");
         // batch 0: all polynomials at zeta
         hipLaunchKernelGGL(k_fri_combine, dim3(gb), dim3(256), 0, st, d_cols.as<const gl_t*>(), d_apow.as<gl_t>(), (uint32_t)nopen, (uint32_t)n, Fa, Fb);
-        hipLaunchKernelGGL(k_div_linear_heads, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, zeta.a, zeta.b, d_heads.as<gl_t>());
-        hipLaunchKernelGGL(k_div_linear_carries, dim3(1), dim3(64), 0, st, d_heads.as<gl_t>(), (uint32_t)n, zeta.a, zeta.b);
-        hipLaunchKernelGGL(k_div_linear_apply, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, zeta.a, zeta.b, d_heads.as<gl_t>(), shift.a, shift.b, Qa, Qb, 0);
+        hipLaunchKernelGGL(k_div_linear_heads, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, seg_len, zeta.a, zeta.b, d_heads.as<gl_t>());
+        hipLaunchKernelGGL(k_div_linear_carries, dim3(1), dim3(1024), 0, st, d_heads.as<gl_t>(), (uint32_t)n, seg_len, zeta.a, zeta.b);
+        hipLaunchKernelGGL(k_div_linear_apply, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, seg_len, zeta.a, zeta.b, d_heads.as<gl_t>(), shift.a, shift.b, Qa, Qb, 0);
         // batch 1: the Z polynomials at g * zeta
         hipLaunchKernelGGL(k_fri_combine, dim3(gb), dim3(256), 0, st, d_cols.as<const gl_t*>() + nopen, d_apow.as<gl_t>() + 2 * nopen, 2u, (uint32_t)n, Fa, Fb);
-        hipLaunchKernelGGL(k_div_linear_heads, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, gzeta.a, gzeta.b, d_heads.as<gl_t>());
-        hipLaunchKernelGGL(k_div_linear_carries, dim3(1), dim3(64), 0, st, d_heads.as<gl_t>(), (uint32_t)n, gzeta.a, gzeta.b);
-        hipLaunchKernelGGL(k_div_linear_apply, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, gzeta.a, gzeta.b, d_heads.as<gl_t>(), (gl_t)1, (gl_t)0, Qa, Qb, 1);
+        hipLaunchKernelGGL(k_div_linear_heads, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, seg_len, gzeta.a, gzeta.b, d_heads.as<gl_t>());
+        hipLaunchKernelGGL(k_div_linear_carries, dim3(1), dim3(1024), 0, st, d_heads.as<gl_t>(), (uint32_t)n, seg_len, gzeta.a, gzeta.b);
+        hipLaunchKernelGGL(k_div_linear_apply, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, seg_len, gzeta.a, gzeta.b, d_heads.as<gl_t>(), (gl_t)1, (gl_t)0, Qa, Qb, 1);
         ctx->timing_end();
         GL_CHECK_HIP(hipGetLastError());
         GL_CHECK_HIP(hipStreamSynchronize(st));

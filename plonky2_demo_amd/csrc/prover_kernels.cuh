@@ -353,43 +353,61 @@ __global__ __launch_bounds__(256) void k_fri_combine(const gl_t* const* cols, co
     out_a[i] = gl_canon(a); out_b[i] = gl_canon(b);
 }
 
-// (F(X) - F(z)) / (X - z) by segmented backward Horner: b_i = b_{i+1} z + c_i, quotient[i] = b_{i+1}, quotient[n-1] = 0
-#define GLP_DIV_SEG 64
+// (F(X) - F(z)) / (X - z) by segmented backward Horner: b_i = b_{i+1} z + c_i, quotient[i] = b_{i+1}, quotient[n-1] = 0.
+// Segments of `seg` coefficients (at most 1024 segments).
 // D1: head value of each segment assuming zero carry-in:  L_s = sum_{k in seg} c_k z^(k - start)
-__global__ void k_div_linear_heads(const gl_t* ca, const gl_t* cb, uint32_t n, gl_t za, gl_t zb, gl_t* heads /* [nseg][2] */) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, nseg = (n + GLP_DIV_SEG - 1) / GLP_DIV_SEG;
+__global__ void k_div_linear_heads(const gl_t* ca, const gl_t* cb, uint32_t n, uint32_t seg, gl_t za, gl_t zb, gl_t* heads /* [nseg][2] */) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, nseg = (n + seg - 1) / seg;
     if (s >= nseg) return;
     const gl2_t z = gl2_make(za, zb);
-    const uint32_t lo = s * GLP_DIV_SEG, hi = (lo + GLP_DIV_SEG < n) ? lo + GLP_DIV_SEG : n;
+    const uint32_t lo = s * seg, hi = (lo + seg < n) ? lo + seg : n;
     gl2_t acc = gl2_make(0, 0);
     for (uint32_t k = hi; k > lo; k--) acc = gl2_add(gl2_mul(acc, z), gl2_make(ca[k - 1], cb[k - 1]));
     heads[2 * s] = acc.a; heads[2 * s + 1] = acc.b;
 }
-// D2: carries B_s = b at the start of segment s: B_s = L_s + z^len(s) * B_{s+1}; stores carry-in of each segment
-__global__ void k_div_linear_carries(gl_t* heads, uint32_t n, gl_t za, gl_t zb) {
-    if (threadIdx.x || blockIdx.x) return;
-    const uint32_t nseg = (n + GLP_DIV_SEG - 1) / GLP_DIV_SEG;
+// D2: carry-in of every segment.  With f_s(x) = L_s + z^len(s) x the value of b at the start of segment s is
+// (f_s o f_{s+1} o ... o f_last)(0); compositions of affine maps are associative -> suffix scan in LDS (one workgroup).
+__global__ __launch_bounds__(1024) void k_div_linear_carries(gl_t* heads, uint32_t n, uint32_t seg, gl_t za, gl_t zb) {
+    __shared__ gl_t La[1024], Lb[1024], Za[1024], Zb[1024];
+    const uint32_t s = threadIdx.x, nseg = (n + seg - 1) / seg;
     const gl2_t z = gl2_make(za, zb);
-    const gl2_t zseg = gl2_exp(z, GLP_DIV_SEG);
-    gl2_t carry = gl2_make(0, 0);                    // b_n = 0
-    for (uint32_t s = nseg; s-- > 0;) {
-        const uint32_t lo = s * GLP_DIV_SEG, len = (lo + GLP_DIV_SEG < n) ? GLP_DIV_SEG : n - lo;
-        gl2_t head = gl2_make(heads[2 * s], heads[2 * s + 1]);
-        heads[2 * s] = carry.a; heads[2 * s + 1] = carry.b;                 // carry-in for segment s
-        carry = gl2_add(head, gl2_mul(len == GLP_DIV_SEG ? zseg : gl2_exp(z, len), carry));
+    gl2_t L = gl2_make(0, 0), Z = gl2_make(1, 0);
+    if (s < nseg) {
+        const uint32_t lo = s * seg, len = (lo + seg < n) ? seg : n - lo;
+        L = gl2_make(heads[2 * s], heads[2 * s + 1]);
+        Z = gl2_exp(z, len);
+    }
+    La[s] = L.a; Lb[s] = L.b; Za[s] = Z.a; Zb[s] = Z.b;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        gl2_t L2 = gl2_make(0, 0), Z2 = gl2_make(1, 0);
+        const bool has = s + d < 1024;
+        if (has) { L2 = gl2_make(La[s + d], Lb[s + d]); Z2 = gl2_make(Za[s + d], Zb[s + d]); }
+        __syncthreads();
+        if (has) {      // (L, Z) o (L2, Z2) = (L + Z L2, Z Z2)
+            L = gl2_add(L, gl2_mul(Z, L2));
+            Z = gl2_mul(Z, Z2);
+            La[s] = L.a; Lb[s] = L.b; Za[s] = Z.a; Zb[s] = Z.b;
+        }
+        __syncthreads();
+    }
+    // carry-in of segment s = b at the start of segment s+1
+    if (s < nseg) {
+        gl_t ca = 0, cb = 0;
+        if (s + 1 < nseg) { ca = La[s + 1]; cb = Lb[s + 1]; }
+        heads[2 * s] = gl_canon(ca); heads[2 * s + 1] = gl_canon(cb);
     }
 }
-// D3: exact recurrence inside each segment, writing the quotient; result = scale * quotient (+ addend if given)
-__global__ void k_div_linear_apply(const gl_t* ca, const gl_t* cb, uint32_t n, gl_t za, gl_t zb, const gl_t* carries,
+// D3: exact recurrence inside each segment, writing scale * quotient (+ what is already there if accumulate)
+__global__ void k_div_linear_apply(const gl_t* ca, const gl_t* cb, uint32_t n, uint32_t seg, gl_t za, gl_t zb, const gl_t* carries,
                                    gl_t sa, gl_t sb, gl_t* qa, gl_t* qb, int accumulate) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, nseg = (n + GLP_DIV_SEG - 1) / GLP_DIV_SEG;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, nseg = (n + seg - 1) / seg;
     if (s >= nseg) return;
     const gl2_t z = gl2_make(za, zb), scale = gl2_make(sa, sb);
-    const uint32_t lo = s * GLP_DIV_SEG, hi = (lo + GLP_DIV_SEG < n) ? lo + GLP_DIV_SEG : n;
+    const uint32_t lo = s * seg, hi = (lo + seg < n) ? lo + seg : n;
     gl2_t b = gl2_make(carries[2 * s], carries[2 * s + 1]);          // b_hi
     for (uint32_t k = hi; k > lo; k--) {
-        // quotient[k-1] = b_k
-        gl2_t q = gl2_mul(b, scale);
+        gl2_t q = gl2_mul(b, scale);                                  // quotient[k-1] = b_k
         if (accumulate) q = gl2_add(q, gl2_make(qa[k - 1], qb[k - 1]));
         qa[k - 1] = gl_canon(q.a); qb[k - 1] = gl_canon(q.b);
         b = gl2_add(gl2_mul(b, z), gl2_make(ca[k - 1], cb[k - 1]));
