@@ -448,6 +448,25 @@ class CircuitData:
             pass
 
 
+class CircuitView:
+    """The same device-resident CircuitData used from another context (stream) of the same device."""
+
+    def __init__(self, circuit_data, ctx):
+        self.cd, self.ctx = circuit_data, ctx
+
+    def prove_device(self, d_wires_ptr, public_inputs):
+        pis = _u64(public_inputs)
+        h = ctypes.c_void_p()
+        check(lib.gl_prove_device(self.ctx.handle, self.cd.handle, d_wires_ptr, _p(pis), pis.size, ctypes.byref(h)))
+        return Proof(h.value, self.cd.host.n)
+
+    def prove(self, wires, public_inputs):
+        wires, pis = _u64(wires), _u64(public_inputs)
+        h = ctypes.c_void_p()
+        check(lib.gl_prove(self.ctx.handle, self.cd.handle, _p(wires), _p(pis), pis.size, ctypes.byref(h)))
+        return Proof(h.value, self.cd.host.n)
+
+
 class Proof:
     def __init__(self, handle, n):
         self.handle, self.n = handle, n

@@ -41,8 +41,8 @@ static int batch_alloc(gl_ctx* c, size_t ncols, size_t n, uint32_t rate_bits, ui
     GL_TRY(c->activate());
     gl_batch* b = new gl_batch();
     b->ctx = c; b->ncols = ncols; b->n = n; b->degree_log = lg; b->rate_bits = rate_bits; b->cap_height = cap_height;
-    GL_CHECK_HIP(hipMalloc((void**)&b->coeffs, ncols * n * sizeof(gl_t)));
-    GL_CHECK_HIP(hipMalloc((void**)&b->lde, ncols * b->N() * sizeof(gl_t)));
+    GL_TRY(c->pool_alloc(ncols * n * sizeof(gl_t), (void**)&b->coeffs));
+    GL_TRY(c->pool_alloc(ncols * b->N() * sizeof(gl_t), (void**)&b->lde));
     *out = b;
     return GL_OK;
 }
@@ -138,10 +138,8 @@ extern "C" const uint64_t* gl_batch_dev_coeffs(const gl_batch* b) { return b ? b
 extern "C" const uint64_t* gl_batch_dev_lde(const gl_batch* b) { return b ? b->lde : nullptr; }
 extern "C" void gl_batch_free(gl_batch* b) {
     if (!b) return;
-    (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
-    gl_merkle_release(&b->tree);
-    if (b->coeffs) (void)hipFree(b->coeffs);
-    if (b->lde) (void)hipFree(b->lde);
+    gl_merkle_release(b->ctx, &b->tree);
+    b->ctx->pool_release(b->coeffs);
+    b->ctx->pool_release(b->lde);
     delete b;
 }

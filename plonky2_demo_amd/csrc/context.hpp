@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <map>
+#include <mutex>
+#include <unordered_map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -68,6 +70,18 @@ struct gl_ctx {
     void timing_begin(const char* name);
     void timing_end();
 
+    // Stream-ordered caching allocator: prove() allocates the same buffer sizes for every proof, and hipMalloc /
+    // hipFree synchronise the whole device (which would serialise proofs running on other streams).  Blocks are
+    // recycled within this context only; all work of a context is ordered on its one stream, so a block may be
+    // handed out again without waiting for the kernels that last used it.
+    std::mutex pool_mu;
+    std::multimap<size_t, void*> pool_free_blocks;
+    std::unordered_map<void*, size_t> pool_block_size;
+    size_t pool_bytes = 0;
+    int pool_alloc(size_t bytes, void** out);
+    void pool_release(void* p);
+    void pool_trim();
+
     int activate();
     int ensure_scratch(size_t elems);
     int ensure_pinned(size_t bytes);
@@ -96,7 +110,7 @@ struct GlMerkle {
 // leaf r (natural order) has elements base[offsets[e] + r], e < leaf_len; it is leaf bitrev(r) of the tree
 int gl_merkle_build(gl_ctx* ctx, const gl_t* base, const uint64_t* host_offsets, uint32_t leaf_len,
                     uint32_t lg_leaves, uint32_t cap_height, GlMerkle* out);
-void gl_merkle_release(GlMerkle* m);
+void gl_merkle_release(gl_ctx* ctx, GlMerkle* m);
 int gl_merkle_prove_impl(gl_ctx* c, const GlMerkle& m, size_t leaf_index, uint64_t* h_out, uint32_t* n_siblings);
 
 // ---- PolynomialBatch (batch.hip) ------------------------------------------------------------------------

@@ -102,7 +102,7 @@ int gl_merkle_build(gl_ctx* c, const gl_t* base, const uint64_t* host_offsets, u
     uint64_t off = 0;
     for (uint32_t l = 0; l < levels; l++) { out->level_off[l] = off; off += uint64_t(1) << (lg_leaves - l); }
     out->total_digests = off;
-    GL_CHECK_HIP(hipMalloc((void**)&out->digests, off * 4 * sizeof(gl_t)));
+    GL_TRY(c->pool_alloc(off * 4 * sizeof(gl_t), (void**)&out->digests));
     // offsets -> device: tiny table, cached per content in the context (no sync in steady state)
     const uint64_t* d_off = nullptr;
     GL_TRY(c->get_offsets_table(host_offsets, leaf_len, &d_off));
@@ -120,8 +120,8 @@ int gl_merkle_build(gl_ctx* c, const gl_t* base, const uint64_t* host_offsets, u
     GL_CHECK_HIP(hipGetLastError());
     return GL_OK;
 }
-void gl_merkle_release(GlMerkle* m) {
-    if (m && m->digests) { (void)hipFree(m->digests); m->digests = nullptr; }
+void gl_merkle_release(gl_ctx* c, GlMerkle* m) {
+    if (m && m->digests) { c->pool_release(m->digests); m->digests = nullptr; }
 }
 
 // --------------------------------------------------------------------------------------------- C ABI
@@ -212,7 +212,7 @@ extern "C" void gl_merkle_free(gl_merkle* t) {
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);
-    gl_merkle_release(&t->tree);
+    gl_merkle_release(t->ctx, &t->tree);
     if (t->leaves) (void)hipFree(t->leaves);
     delete t;
 }

@@ -63,6 +63,45 @@ int gl_ctx::get_pow_table(gl_t base, gl_t scale, uint32_t hi_len, GlPowTable* ou
     return GL_OK;
 }
 
+int gl_ctx::pool_alloc(size_t bytes, void** out) {
+    const size_t gran = bytes >= (size_t(1) << 20) ? (size_t(1) << 20) : (size_t(1) << 12);
+    const size_t want = ((bytes ? bytes : 8) + gran - 1) / gran * gran;
+    {
+        std::lock_guard<std::mutex> lk(pool_mu);
+        auto it = pool_free_blocks.lower_bound(want);
+        if (it != pool_free_blocks.end() && it->first <= want + want / 4) {
+            *out = it->second;
+            pool_free_blocks.erase(it);
+            return GL_OK;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {          // out of memory: drop the cache and retry once
+        pool_trim();
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) return gl_fail(GL_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__);
+    std::lock_guard<std::mutex> lk(pool_mu);
+    pool_block_size[p] = want;
+    pool_bytes += want;
+    *out = p;
+    return GL_OK;
+}
+void gl_ctx::pool_release(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(pool_mu);
+    auto it = pool_block_size.find(p);
+    if (it == pool_block_size.end()) { (void)hipFree(p); return; }
+    pool_free_blocks.emplace(it->second, p);
+}
+void gl_ctx::pool_trim() {
+    std::lock_guard<std::mutex> lk(pool_mu);
+    (void)hipStreamSynchronize(stream);
+    for (auto& kv : pool_free_blocks) { pool_bytes -= kv.first; pool_block_size.erase(kv.second); (void)hipFree(kv.second); }
+    pool_free_blocks.clear();
+}
+
 void gl_ctx::timing_begin(const char* name) {
     if (!timing_enabled) return;
     TimingRec r; r.name = name;
@@ -163,6 +202,8 @@ extern "C" void gl_ctx_destroy(gl_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (int d = 0; d < 2; d++) if (c->tw_local[d]) (void)hipFree(c->tw_local[d]);
+    c->pool_trim();
+    for (auto& kv : c->pool_block_size) (void)hipFree(kv.first);      // blocks still held by live handles
     for (auto& kv : c->pow_tables) (void)hipFree(kv.second.lo);
     for (auto& kv : c->offset_tables) (void)hipFree(kv.second);
     if (c->scratch) (void)hipFree(c->scratch);

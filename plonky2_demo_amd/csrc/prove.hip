@@ -97,7 +97,7 @@ static int validate_desc(const gl_circuit_desc& d) {
 extern "C" void gl_circuit_free(gl_circuit* c) {
     if (!c) return;
     if (c->cs_batch) gl_batch_free(c->cs_batch);
-    if (c->d_sigmas) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); (void)hipFree(c->d_sigmas); }
+    if (c->d_sigmas) c->ctx->pool_release(c->d_sigmas);
     delete c;
 }
 
@@ -111,7 +111,7 @@ extern "C" int gl_circuit_create(gl_ctx* ctx, const gl_circuit_desc* desc, const
     std::vector<const uint64_t*> cols(ncs);
     for (size_t k = 0; k < ncs; k++) cols[k] = h_cs + k * n;
     GL_TRY(gl_batch_from_values(ctx, cols.data(), ncs, n, desc->rate_bits, 0, desc->cap_height, &c->cs_batch));   // circuit_builder.rs:1020-1028
-    GL_CHECK_HIP(hipMalloc((void**)&c->d_sigmas, 80 * n * sizeof(gl_t)));
+    GL_TRY(ctx->pool_alloc(80 * n * sizeof(gl_t), (void**)&c->d_sigmas));
     GL_TRY(gl_copy_h2d(ctx, c->d_sigmas, h_cs + (size_t)desc->num_constants * n, 80 * n * sizeof(gl_t)));
     // circuit_digest = hash_no_pad(cap || hash_pad([]) || [degree_bits])   (circuit_builder.rs:1089-1100)
     std::vector<gl_t> parts((size_t(4) << desc->cap_height));
@@ -145,14 +145,16 @@ static void put_u64(std::vector<uint8_t>& o, uint64_t v) { for (int i = 0; i < 8
 static void put_words(std::vector<uint8_t>& o, const gl_t* v, size_t n) { for (size_t i = 0; i < n; i++) put_u64(o, gl_canon(v[i])); }
 static uint32_t host_bitrev32(uint32_t x, uint32_t bits) { uint32_t r = 0; for (uint32_t i = 0; i < bits; i++) r = (r << 1) | ((x >> i) & 1); return r; }
 
-struct DevBuf {                     // RAII device allocation on the ctx's device
-    void* p = nullptr;
-    int alloc(size_t bytes) { GL_CHECK_HIP(hipMalloc(&p, bytes ? bytes : 8)); return GL_OK; }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+struct DevBuf {                     // RAII block from the context's stream-ordered pool
+    gl_ctx* c; void* p = nullptr;
+    explicit DevBuf(gl_ctx* ctx) : c(ctx) {}
+    int alloc(size_t bytes) { return c->pool_alloc(bytes, &p); }
+    void release() { if (p) { c->pool_release(p); p = nullptr; } }
+    ~DevBuf() { release(); }
     template <class T> T* as() const { return (T*)p; }
 };
 struct BatchHolder { gl_batch* b = nullptr; ~BatchHolder() { if (b) gl_batch_free(b); } };
-struct MerkleHolder { GlMerkle m; ~MerkleHolder() { gl_merkle_release(&m); } };
+struct MerkleHolder { gl_ctx* c; GlMerkle m; explicit MerkleHolder(gl_ctx* ctx) : c(ctx) {} ~MerkleHolder() { gl_merkle_release(c, &m); } };
 
 static int d2h(gl_ctx* c, void* dst, const void* src, size_t bytes) { return gl_copy_d2h(c, dst, src, bytes); }
 static int h2d_async(gl_ctx* c, void* dst, const void* src, size_t bytes) {
@@ -179,9 +181,12 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     const uint32_t lgn = d.degree_bits, lgN = lgn + d.rate_bits, ncap = 4u << d.cap_height;
     hipStream_t st = ctx->stream;
     std::unique_ptr<gl_proof> proof(new gl_proof());
+    // small host tables uploaded with async copies stay alive until the function returns (after the last sync)
+    std::vector<gl_t> h_apow_quot, h_apow_fri;
+    std::vector<const gl_t*> h_cols;
 
     // ---- 4. wires commitment (prover.rs:145-156) ----
-    DevBuf d_wit; GL_TRY(d_wit.alloc(135 * n * sizeof(gl_t)));
+    DevBuf d_wit(ctx); GL_TRY(d_wit.alloc(135 * n * sizeof(gl_t)));
     ctx->timing_begin("H2D witness");
     GL_CHECK_HIP(hipMemcpyAsync(d_wit.p, h_wires, 135 * n * sizeof(gl_t), wires_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     ctx->timing_end();
@@ -201,9 +206,9 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     for (int i = 0; i < 2; i++) gammas[i] = ch.challenge();
 
     // ---- 6/7. partial products and Z, commitment (prover.rs:189-223) ----
-    DevBuf d_zs; GL_TRY(d_zs.alloc(20 * n * sizeof(gl_t)));
+    DevBuf d_zs(ctx); GL_TRY(d_zs.alloc(20 * n * sizeof(gl_t)));
     {
-        DevBuf d_chunk, d_rowp, d_seg;
+        DevBuf d_chunk(ctx), d_rowp(ctx), d_seg(ctx);
         const uint32_t nseg = (uint32_t)((n + GLP_SEG - 1) / GLP_SEG);
         GL_TRY(d_chunk.alloc(2 * GLP_CHUNKS * n * sizeof(gl_t)));
         GL_TRY(d_rowp.alloc(2 * n * sizeof(gl_t)));
@@ -222,7 +227,6 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
         hipLaunchKernelGGL(k_z_finalize, dim3(nseg, 2), dim3(256), 0, st, d_rowp.as<gl_t>(), d_chunk.as<gl_t>(), d_seg.as<gl_t>(), (uint32_t)n, d_zs.as<gl_t>());
         ctx->timing_end();
         GL_CHECK_HIP(hipGetLastError());
-        GL_CHECK_HIP(hipStreamSynchronize(st));       // temporaries are released at scope exit
     }
     proof->zs_pp.resize(20 * n);
     GL_TRY(d2h(ctx, proof->zs_pp.data(), d_zs.p, 20 * n * sizeof(gl_t)));
@@ -233,9 +237,9 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     for (int i = 0; i < 2; i++) alphas[i] = ch.challenge();
 
     // ---- 9/10. quotient polynomials (prover.rs:229-271) ----
-    DevBuf d_q; GL_TRY(d_q.alloc(2 * N * sizeof(gl_t)));
+    DevBuf d_q(ctx); GL_TRY(d_q.alloc(2 * N * sizeof(gl_t)));
     {
-        std::vector<gl_t> apow(2 * GLQ_MAX_TERMS);
+        std::vector<gl_t>& apow = h_apow_quot; apow.assign(2 * GLQ_MAX_TERMS, 0);
         for (int b = 0; b < 2; b++) { gl_t x = 1; for (int t = 0; t < GLQ_MAX_TERMS; t++) { apow[b * GLQ_MAX_TERMS + t] = x; x = gl_canon(gl_mul(x, alphas[b])); } }
         GL_TRY(ctx->ensure_dev_small(1 << 20));
         gl_t* d_apow = ctx->dev_small;
@@ -309,19 +313,19 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
 
     // ---- 14. prove_openings (fri/oracle.rs:162-219) ----
     gl2_t fri_alpha; fri_alpha.a = ch.challenge(); fri_alpha.b = ch.challenge();
-    DevBuf d_final;    GL_TRY(d_final.alloc(2 * n * sizeof(gl_t)));            // planes a, b of alpha^2 Q0 + Q1
+    DevBuf d_final(ctx);    GL_TRY(d_final.alloc(2 * n * sizeof(gl_t)));            // planes a, b of alpha^2 Q0 + Q1
     {
-        DevBuf d_F, d_heads, d_cols, d_apow;
+        DevBuf d_F(ctx), d_heads(ctx), d_cols(ctx), d_apow(ctx);
         const uint32_t seg_len = (uint32_t)(n / 1024 > 32 ? n / 1024 : (n >= 32 ? 32 : n));      // at most 1024 segments
         const uint32_t nseg = (uint32_t)((n + seg_len - 1) / seg_len);
         GL_TRY(d_F.alloc(2 * n * sizeof(gl_t)));
         GL_TRY(d_heads.alloc(2 * (size_t)nseg * sizeof(gl_t)));
         GL_TRY(d_cols.alloc((nopen + 2) * sizeof(gl_t*)));
         GL_TRY(d_apow.alloc(2 * (nopen + 2) * sizeof(gl_t)));
-        std::vector<const gl_t*> cols;
+        std::vector<const gl_t*>& cols = h_cols;
         for (int o = 0; o < 4; o++) for (size_t c = 0; c < oracles[o]->ncols; c++) cols.push_back(oracles[o]->coeffs + c * n);
         cols.push_back(zs.b->coeffs); cols.push_back(zs.b->coeffs + n);
-        std::vector<gl_t> apow(2 * (nopen + 2));
+        std::vector<gl_t>& apow = h_apow_fri; apow.assign(2 * (nopen + 2), 0);
         { gl2_t x = gl2_make(1, 0); for (size_t j = 0; j < nopen; j++) { apow[2 * j] = x.a; apow[2 * j + 1] = x.b; x = gl2_canon(gl2_mul(x, fri_alpha)); } }
         { gl2_t x = gl2_make(1, 0); for (size_t j = 0; j < 2; j++) { apow[2 * (nopen + j)] = x.a; apow[2 * (nopen + j) + 1] = x.b; x = gl2_canon(gl2_mul(x, fri_alpha)); } }
         GL_TRY(h2d_async(ctx, d_cols.p, cols.data(), cols.size() * sizeof(gl_t*)));
@@ -343,10 +347,9 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
         hipLaunchKernelGGL(k_div_linear_apply, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, seg_len, gzeta.a, gzeta.b, d_heads.as<gl_t>(), (gl_t)1, (gl_t)0, Qa, Qb, 1);
         ctx->timing_end();
         GL_CHECK_HIP(hipGetLastError());
-        GL_CHECK_HIP(hipStreamSynchronize(st));
     }
     // final_poly.lde(rate_bits).coset_fft(7) on both planes (fri/oracle.rs:199-204)
-    DevBuf d_vals; GL_TRY(d_vals.alloc(2 * N * sizeof(gl_t)));
+    DevBuf d_vals(ctx); GL_TRY(d_vals.alloc(2 * N * sizeof(gl_t)));
     GL_TRY(gl_ntt_run(ctx, d_final.as<gl_t>(), n, (uint32_t)n, d_vals.as<gl_t>(), N, lgN, 2, false, GL_MULT_GENERATOR, 0, 1));
 
     // ---- fri_committed_trees (fri/prover.rs:69-112) ----
@@ -354,9 +357,9 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     std::vector<std::unique_ptr<DevBuf>> fri_vals;          // value planes of each round (kept for the query phase)
     std::vector<uint32_t> fri_lg;                           // log2 of each round's value length
     std::vector<gl_t> fri_caps, fri_betas;
-    std::unique_ptr<DevBuf> cur_vals(new DevBuf());
+    std::unique_ptr<DevBuf> cur_vals(new DevBuf(ctx));
     cur_vals->p = d_vals.p; d_vals.p = nullptr;
-    DevBuf coef_a, coef_b;                                  // ping-pong coefficient planes [2][cur_n]
+    DevBuf coef_a(ctx), coef_b(ctx);                        // ping-pong coefficient planes [2][cur_n]
     coef_a.p = d_final.p; d_final.p = nullptr;
     size_t cur_n = n;                                       // non-zero coefficients
     uint32_t cur_lgN = lgN;
@@ -368,7 +371,7 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
         std::vector<uint64_t> offs(2 * arity);
         for (uint32_t k = 0; k < arity; k++)
             for (uint32_t cpt = 0; cpt < 2; cpt++) offs[2 * k + cpt] = (uint64_t)cpt * curN + (uint64_t)host_bitrev32(k, ab) * (curN >> ab);
-        std::unique_ptr<MerkleHolder> tree(new MerkleHolder());
+        std::unique_ptr<MerkleHolder> tree(new MerkleHolder(ctx));
         GL_TRY(gl_merkle_build(ctx, cur_vals->as<gl_t>(), offs.data(), 2 * arity, cur_lgN - ab, d.cap_height, &tree->m));
         GL_TRY(d2h(ctx, cap.data(), tree->m.level_ptr(tree->m.num_levels() - 1), ncap * sizeof(gl_t)));
         fri_caps.insert(fri_caps.end(), cap.begin(), cap.end());
@@ -387,12 +390,11 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
         shift = gl_canon(gl_exp(shift, arity));
         fri_trees.push_back(std::move(tree)); fri_vals.push_back(std::move(cur_vals)); fri_lg.push_back(cur_lgN);
         cur_lgN -= ab;
-        cur_vals.reset(new DevBuf());
+        cur_vals.reset(new DevBuf(ctx));
         GL_TRY(cur_vals->alloc(2 * (size_t(1) << cur_lgN) * sizeof(gl_t)));
         GL_TRY(gl_ntt_run(ctx, coef_b.as<gl_t>(), next_n, (uint32_t)next_n, cur_vals->as<gl_t>(), size_t(1) << cur_lgN, cur_lgN, 2, false, shift, 0, 1));
-        GL_CHECK_HIP(hipStreamSynchronize(st));
         std::swap(coef_a.p, coef_b.p);
-        (void)hipFree(coef_b.p); coef_b.p = nullptr;
+        coef_b.release();
         cur_n = next_n;
     }
     // final polynomial: the remaining non-zero coefficients (coeffs.truncate(len >> rate_bits), fri/prover.rs:106-111)
@@ -450,7 +452,7 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
         fleaf_piece[r] = {total, (size_t)nq * (2u << ab)}; total += fleaf_piece[r].words;
         fpath_piece[r] = {total, (size_t)nq * lv * 4}; total += fpath_piece[r].words;
     }
-    DevBuf d_stage, d_idx;
+    DevBuf d_stage(ctx), d_idx(ctx);
     GL_TRY(d_stage.alloc((total + 8) * sizeof(gl_t)));
     GL_TRY(d_idx.alloc((size_t)nq * (2 + d.num_fri_rounds) * sizeof(uint32_t)));
     std::vector<uint32_t> idx_host((size_t)nq * (2 + d.num_fri_rounds));
