@@ -14,8 +14,10 @@
 #if defined(__HIPCC__)
 // device copies of the tables (per translation unit, constant address space -> scalar loads)
 #define POSEIDON_TABLE(name, n) static __constant__ const uint64_t d_##name[n]
+#define POSEIDON_TABLE32(name, n) static __constant__ const uint32_t d_##name[n]
 #include "poseidon_constants.inc"
 #undef POSEIDON_TABLE
+#undef POSEIDON_TABLE32
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -59,34 +61,91 @@ GL_HD void psd_full_round(gl_t (&s)[12], int round) {
     psd_mds(s);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Carry-free dot products for the GPU: every 64-bit table constant is split into 22-bit limbs (c = l0 + l1 2^22 +
+// l2 2^44) and every state word into 32-bit halves, so that the six partial sums
+//   A0 = sum lo*l0, A1 = sum lo*l1, A2 = sum lo*l2, A3 = sum hi*l0, A4 = sum hi*l1, A5 = sum hi*l2     (each < 12 * 2^54)
+// fit 64-bit registers and are accumulated by plain v_mad_u64_u32 with scalar constants -- no carries, no
+// reduction per term.  value = A0 + A1 2^22 + A2 2^44 + (A3 + A4 2^22 + A5 2^44) 2^32, reduced once.
+struct PsdDot { gl_t a0, a1, a2, a3, a4, a5; };
+__device__ __forceinline__ void psd_dot_term(PsdDot& d, gl_t s, const uint32_t* __restrict__ limbs) {
+    const uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
+    const uint32_t l0 = limbs[0], l1 = limbs[1], l2 = limbs[2];
+    d.a0 += (gl_t)lo * l0; d.a1 += (gl_t)lo * l1; d.a2 += (gl_t)lo * l2;
+    d.a3 += (gl_t)hi * l0; d.a4 += (gl_t)hi * l1; d.a5 += (gl_t)hi * l2;
+}
+// a + (b << 22) + (c << 44) as a 128-bit number (a, b, c < 2^58)
+__device__ __forceinline__ void psd_dot_fold3(gl_t a, gl_t b, gl_t c, gl_t& lo, gl_t& hi) {
+    gl_t l = a + (b << 22);
+    gl_t h = (b >> 42) + ((l < a) ? 1 : 0);
+    gl_t l2 = l + (c << 44);
+    h += (c >> 20) + ((l2 < l) ? 1 : 0);
+    lo = l2; hi = h;
+}
+__device__ __forceinline__ gl_t psd_dot_reduce(const PsdDot& d) {
+    gl_t lo0, hi0, lo1, hi1;
+    psd_dot_fold3(d.a0, d.a1, d.a2, lo0, hi0);        // hi0 < 2^39
+    psd_dot_fold3(d.a3, d.a4, d.a5, lo1, hi1);        // hi1 < 2^39
+    // V = lo0 + hi0 2^64 + (lo1 + hi1 2^64) 2^32,  2^96 = -1 (mod p)
+    gl_t x = lo0 + (lo1 << 32);
+    gl_t h = hi0 + (lo1 >> 32) + ((x < lo0) ? 1 : 0);    // < 2^41
+    gl_t r = gl_reduce128(x, h);
+    return gl_sub_c(r, hi1);                              // hi1 is canonical (< 2^39)
+}
+#endif
+
 GL_HD void psd_partial_rounds(gl_t (&s)[12]) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_add_c(s[i], PSD_TAB(POSEIDON_PARTIAL_FIRST_RC)[i]);
-    {
+#if defined(__HIP_DEVICE_COMPILE__)
+    {   // dense 11x11 pre-matrix: one dot product per output word, looped to keep the scalar constants few
         gl_t t[12];
         t[0] = s[0];
-#pragma unroll
+#pragma unroll 1
         for (int c = 1; c < 12; c++) {
-            gl_t acc = 0;
+            PsdDot d = {0, 0, 0, 0, 0, 0};
+            const uint32_t* lm = d_POSEIDON_PARTIAL_INIT_T_LIMBS + (c - 1) * 33;
 #pragma unroll
-            for (int r = 1; r < 12; r++) acc = gl_mul_add(acc, s[r], PSD_TAB(POSEIDON_PARTIAL_INIT)[(r - 1) * 11 + (c - 1)]);
-            t[c] = acc;
+            for (int r = 1; r < 12; r++) psd_dot_term(d, s[r], lm + 3 * (r - 1));
+            const gl_t v = psd_dot_reduce(d);
+            // scatter into t[c] without dynamic register indexing
+#pragma unroll
+            for (int k = 1; k < 12; k++) if (k == c) t[k] = v;
         }
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = t[i];
     }
-#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
-#endif
     for (int r = 0; r < POSEIDON_PARTIAL_ROUNDS; r++) {
-        gl_t s0 = gl_add_c(psd_sbox(s[0]), PSD_TAB(POSEIDON_PARTIAL_RC)[r]);
+        const gl_t s0 = gl_add_c(psd_sbox(s[0]), d_POSEIDON_PARTIAL_RC[r]);
+        PsdDot d = {0, 0, 0, 0, 0, 0};
+        d.a0 = (gl_t)(uint32_t)s0 * 25u; d.a3 = (gl_t)(uint32_t)(s0 >> 32) * 25u;      // MDS[0][0] = circ[0] + diag[0] = 25
+        const uint32_t* lm = d_POSEIDON_PARTIAL_ROW_LIMBS + r * 33;
+#pragma unroll
+        for (int i = 1; i < 12; i++) psd_dot_term(d, s[i], lm + 3 * (i - 1));
+#pragma unroll
+        for (int i = 1; i < 12; i++) s[i] = gl_mul_add(s[i], s0, d_POSEIDON_PARTIAL_COL[r * 11 + i - 1]);
+        s[0] = psd_dot_reduce(d);
+    }
+#else
+    {
+        gl_t t[12];
+        t[0] = s[0];
+        for (int c = 1; c < 12; c++) {
+            gl_t acc = 0;
+            for (int r = 1; r < 12; r++) acc = gl_mul_add(acc, s[r], POSEIDON_PARTIAL_INIT[(r - 1) * 11 + (c - 1)]);
+            t[c] = acc;
+        }
+        for (int i = 0; i < 12; i++) s[i] = t[i];
+    }
+    for (int r = 0; r < POSEIDON_PARTIAL_ROUNDS; r++) {
+        gl_t s0 = gl_add_c(psd_sbox(s[0]), POSEIDON_PARTIAL_RC[r]);
         gl_t d = gl_mul_small(s0, 17 + 8);   // MDS[0][0] = circ[0] + diag[0]
-#pragma unroll
-        for (int i = 1; i < 12; i++) d = gl_mul_add(d, s[i], PSD_TAB(POSEIDON_PARTIAL_ROW)[r * 11 + i - 1]);
-#pragma unroll
-        for (int i = 1; i < 12; i++) s[i] = gl_mul_add(s[i], s0, PSD_TAB(POSEIDON_PARTIAL_COL)[r * 11 + i - 1]);
+        for (int i = 1; i < 12; i++) d = gl_mul_add(d, s[i], POSEIDON_PARTIAL_ROW[r * 11 + i - 1]);
+        for (int i = 1; i < 12; i++) s[i] = gl_mul_add(s[i], s0, POSEIDON_PARTIAL_COL[r * 11 + i - 1]);
         s[0] = d;
     }
+#endif
 }
 
 GL_HD void psd_permute(gl_t (&s)[12]) {
