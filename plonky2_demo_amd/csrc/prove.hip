@@ -415,7 +415,9 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
         for (int i = 0; i < 12; i++) pw.state[i] = ch.state[i];
         for (int i = 0; i < ch.nin; i++) pw.state[i] = ch.in[i];
         pw.pos = (uint32_t)ch.nin; pw.min_leading_zeros = d.proof_of_work_bits; pw.result = d_res;
-        const uint64_t batch = uint64_t(1) << 20;
+        // expected 2^pow_bits candidates: scan ascending windows of 2 * 2^pow_bits (86 % hit rate each) so that little work
+        // is wasted; the window's atomicMin keeps the result the global minimum
+        const uint64_t batch = uint64_t(2) << d.proof_of_work_bits;
         unsigned long long res = ~0ull;
         ctx->timing_begin("find proof-of-work witness");
         for (uint64_t base = 0; base < GL_P; base += batch) {
