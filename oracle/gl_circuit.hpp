@@ -94,7 +94,8 @@ struct CircuitBuilder {
         gate_instances.push_back({t, {c0, c1}});
         return row;
     }
-    void connect(Target x, Target y) { copy_constraints.push_back({x, y}); }      // :424-436
+    bool record_copies = true;          // false for a verifier-only build (CommonData without sigmas / commitment)
+    void connect(Target x, Target y) { if (record_copies) copy_constraints.push_back({x, y}); }      // :424-436
     Target constant(u64 c) {                                                      // :485-496
         c = canon(c);
         auto it = constants_to_targets.find(c);
@@ -172,8 +173,10 @@ static inline std::vector<unsigned> fri_reduction_arity_bits(const CircuitConfig
 }
 
 // Builds the m x m matmul circuit exactly as the demo does, then runs build().
-static inline CircuitData build_matmul_circuit(size_t m, unsigned threads = 1) {
+// `prover_data = false` builds only what the verifier needs (CommonData): no copy constraints, sigmas or commitment.
+static inline CircuitData build_matmul_circuit(size_t m, unsigned threads = 1, bool prover_data = true) {
     CircuitBuilder b;
+    b.record_copies = prover_data;
     CircuitData cd;
     cd.m = m;
     std::vector<std::vector<Target>> A(m), B(m), C(m);
@@ -255,10 +258,15 @@ static inline CircuitData build_matmul_circuit(size_t m, unsigned threads = 1) {
     }
     cm.num_constants = constant_vecs.size();
 
+    { u64 x = 1; for (size_t i = 0; i < cfg.num_routed_wires; i++) { cm.k_is.push_back(x); x = mul(x, GL_GENERATOR); } }
+    cm.num_gate_constraints = 0;
+    for (auto g : gates) cm.num_gate_constraints = std::max(cm.num_gate_constraints, gate_num_constraints(g));
+    cm.num_partial_products = (cfg.num_routed_wires + cm.quotient_degree_factor - 1) / cm.quotient_degree_factor - 1;   // partial_products.rs:40-47
+    cm.num_public_inputs = b.public_inputs.size();
+    if (!prover_data) { cd.pi_row = pi_row; return cd; }
     // subgroup, k_is (cosets.rs:9-24), sigma polynomials (permutation_argument.rs)
     cd.subgroup.resize(degree);
     { u64 g = primitive_root_of_unity(degree_bits), x = 1; for (size_t i = 0; i < degree; i++) { cd.subgroup[i] = x; x = mul(x, g); } }
-    { u64 x = 1; for (size_t i = 0; i < cfg.num_routed_wires; i++) { cm.k_is.push_back(x); x = mul(x, GL_GENERATOR); } }
     cd.num_targets = degree * cfg.num_wires + b.virtual_target_index;
     std::vector<size_t>& parent = cd.representative;
     parent.resize(cd.num_targets);
@@ -291,11 +299,6 @@ static inline CircuitData build_matmul_circuit(size_t m, unsigned threads = 1) {
     cd.constants_sigmas = constant_vecs;
     for (auto& v : sigma_vecs) cd.constants_sigmas.push_back(v);
     cd.constants_sigmas_commitment = batch_from_values(cd.constants_sigmas, cfg.rate_bits, cfg.cap_height, threads);   // :1020-1028
-
-    cm.num_gate_constraints = 0;
-    for (auto g : gates) cm.num_gate_constraints = std::max(cm.num_gate_constraints, gate_num_constraints(g));
-    cm.num_partial_products = (cfg.num_routed_wires + cm.quotient_degree_factor - 1) / cm.quotient_degree_factor - 1;   // partial_products.rs:40-47
-    cm.num_public_inputs = b.public_inputs.size();
 
     // circuit digest (:1089-1100): hash_no_pad(cap || hash_pad(domain_separator = []) || [degree_bits])
     {

@@ -396,9 +396,54 @@ static inline std::vector<uint8_t> proof_to_bytes(const Proof& p) {
     return o;
 }
 
+// ProofWithPublicInputs::from_bytes (plonk/proof.rs:112-123; util/serialization Read side): shapes come from CommonData
+static inline bool proof_from_bytes(const CommonData& cm, const uint8_t* b, size_t len, Proof& p) {
+    size_t pos = 0;
+    auto get_u64 = [&](u64& v) { if (pos + 8 > len) return false; v = 0; for (int i = 0; i < 8; i++) v |= (u64)b[pos + i] << (8 * i); pos += 8; return true; };
+    auto get_digests = [&](std::vector<Digest>& v, size_t n) { v.resize(n); for (auto& d : v) for (int k = 0; k < 4; k++) if (!get_u64(d.e[k])) return false; return true; };
+    auto get_ext = [&](std::vector<Ext2>& v, size_t n) { v.resize(n); for (auto& e : v) if (!get_u64(e.a) || !get_u64(e.b)) return false; return true; };
+    auto get_path = [&](std::vector<Digest>& v) { if (pos >= len) return false; size_t n = b[pos++]; return get_digests(v, n); };
+    const CircuitConfig& cfg = cm.config;
+    const size_t ncap = size_t(1) << cfg.cap_height, nch = cfg.num_challenges;
+    if (!get_digests(p.wires_cap, ncap) || !get_digests(p.zs_pp_cap, ncap) || !get_digests(p.quotient_cap, ncap)) return false;
+    OpeningSet& os = p.openings;
+    if (!get_ext(os.constants, cm.num_constants) || !get_ext(os.plonk_sigmas, cfg.num_routed_wires) || !get_ext(os.wires, cfg.num_wires) ||
+        !get_ext(os.plonk_zs, nch) || !get_ext(os.plonk_zs_next, nch) || !get_ext(os.partial_products, nch * cm.num_partial_products) ||
+        !get_ext(os.quotient_polys, nch * cm.quotient_degree_factor)) return false;
+    FriProof& f = p.opening_proof;
+    f.commit_phase_merkle_caps.resize(cm.fri_reduction_arity_bits.size());
+    for (auto& c : f.commit_phase_merkle_caps) if (!get_digests(c, ncap)) return false;
+    const size_t widths[4] = {cm.num_constants + cfg.num_routed_wires, cfg.num_wires, nch * (1 + cm.num_partial_products), nch * cm.quotient_degree_factor};
+    f.query_round_proofs.resize(cfg.num_query_rounds);
+    for (auto& qr : f.query_round_proofs) {
+        qr.initial.resize(4);
+        for (int o = 0; o < 4; o++) {
+            qr.initial[o].first.resize(widths[o]);
+            for (auto& v : qr.initial[o].first) if (!get_u64(v)) return false;
+            if (!get_path(qr.initial[o].second)) return false;
+        }
+        qr.steps.resize(cm.fri_reduction_arity_bits.size());
+        for (size_t i = 0; i < qr.steps.size(); i++) {
+            if (!get_ext(qr.steps[i].evals, size_t(1) << cm.fri_reduction_arity_bits[i])) return false;
+            if (!get_path(qr.steps[i].merkle_proof)) return false;
+        }
+    }
+    if (!get_ext(f.final_poly, cm.final_poly_len()) || !get_u64(f.pow_witness)) return false;
+    u64 npi = 0;
+    if (!get_u64(npi) || npi != cm.num_public_inputs) return false;
+    p.public_inputs.resize(npi);
+    for (auto& v : p.public_inputs) if (!get_u64(v)) return false;
+    return pos == len;
+}
+
 // ---- native verifier (plonk/verifier.rs:15-115, fri/verifier.rs:62-260) --------------------------------------
+static inline const char* verify(const CommonData& cm, const std::vector<Digest>& constants_sigmas_cap, const Digest& circuit_digest, const Proof& p);
 static inline const char* verify(const CircuitData& cd, const Proof& p) {
-    const CommonData& cm = cd.common; const CircuitConfig& cfg = cm.config;
+    return verify(cd.common, cd.constants_sigmas_commitment.tree.cap(), cd.circuit_digest, p);
+}
+// VerifierOnlyCircuitData = (constants_sigmas_cap, circuit_digest) (plonk/circuit_data.rs:333-340)
+static inline const char* verify(const CommonData& cm, const std::vector<Digest>& constants_sigmas_cap, const Digest& circuit_digest, const Proof& p) {
+    const CircuitConfig& cfg = cm.config;
     const size_t nch = cfg.num_challenges, n = cm.degree(), N = n << cfg.rate_bits;
     const OpeningSet& os = p.openings; const FriProof& fp = p.opening_proof;
     // shape (validate_shape.rs)
@@ -411,7 +456,7 @@ static inline const char* verify(const CircuitData& cd, const Proof& p) {
     Digest pi_hash = hash_no_pad(p.public_inputs.data(), p.public_inputs.size());
     // get_challenges (get_challenges.rs:26-87)
     Challenger ch;
-    ch.observe_digest(cd.circuit_digest); ch.observe_digest(pi_hash); ch.observe_cap(p.wires_cap);
+    ch.observe_digest(circuit_digest); ch.observe_digest(pi_hash); ch.observe_cap(p.wires_cap);
     std::vector<u64> betas, gammas, alphas;
     for (size_t i = 0; i < nch; i++) betas.push_back(ch.challenge());
     for (size_t i = 0; i < nch; i++) gammas.push_back(ch.challenge());
@@ -449,7 +494,7 @@ static inline const char* verify(const CircuitData& cd, const Proof& p) {
     std::vector<Ext2> batch0;
     for (auto* v : {&os.constants, &os.plonk_sigmas, &os.wires, &os.plonk_zs, &os.partial_products, &os.quotient_polys}) batch0.insert(batch0.end(), v->begin(), v->end());
     Ext2 red0 = reduce(batch0), red1 = reduce(os.plonk_zs_next);
-    const std::vector<Digest>* caps[4] = {&cd.constants_sigmas_commitment.tree.cap(), &p.wires_cap, &p.zs_pp_cap, &p.quotient_cap};
+    const std::vector<Digest>* caps[4] = {&constants_sigmas_cap, &p.wires_cap, &p.zs_pp_cap, &p.quotient_cap};
     const size_t widths[4] = {cm.num_constants + cfg.num_routed_wires, cfg.num_wires, nch * (1 + cm.num_partial_products), nch * cm.quotient_degree_factor};
     const unsigned log_n = cm.degree_bits + cfg.rate_bits;
     for (unsigned q = 0; q < cfg.num_query_rounds; q++) {

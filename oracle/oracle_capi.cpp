@@ -185,6 +185,23 @@ void orc_batch_level(const void* b, size_t level, u64* out) { write_digests(((co
 struct OrcProof { Proof proof; ProverTrace trace; std::vector<uint8_t> bytes; };
 
 void* orc_circuit_new(size_t m, unsigned threads) { return new CircuitData(build_matmul_circuit(m, threads)); }
+// CommonCircuitData only (what verify() needs besides the cap and the digest): cheap even for m = 128
+void* orc_circuit_new_verifier_only(size_t m) { return new CircuitData(build_matmul_circuit(m, 1, false)); }
+// verify ProofWithPublicInputs bytes against VerifierOnlyCircuitData = (constants_sigmas_cap[2^cap_height][4], circuit_digest[4])
+// 0 = accepted, 1 = rejected, 2 = malformed bytes
+static thread_local const char* g_verify_msg2 = "";
+int orc_verify_bytes(const void* c, const u64* cap, const u64* digest, const uint8_t* bytes, size_t len) {
+    const CircuitData* cd = (const CircuitData*)c;
+    Proof p;
+    if (!proof_from_bytes(cd->common, bytes, len, p)) { g_verify_msg2 = "malformed proof bytes"; return 2; }
+    std::vector<Digest> capv(size_t(1) << cd->common.config.cap_height);
+    memcpy(capv.data(), cap, capv.size() * 32);
+    Digest dg; memcpy(dg.e, digest, 32);
+    const char* m = verify(cd->common, capv, dg, p);
+    g_verify_msg2 = m ? m : "";
+    return m ? 1 : 0;
+}
+const char* orc_verify_bytes_message(void) { return g_verify_msg2; }
 void orc_circuit_free(void* c) { delete (CircuitData*)c; }
 // out: [degree_bits, num_constants, num_gate_constraints, num_partial_products, num_public_inputs, num_selectors,
 //       num_fri_rounds, final_poly_len, pi_row, constant_row, num_arith_ops, num_poseidon_rows]

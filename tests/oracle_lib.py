@@ -122,8 +122,8 @@ class Oracle:
     def batch(self, cols, rate_bits, cap_height, from_values=True, threads=1):
         return OracleBatch(self, cols, rate_bits, cap_height, from_values, threads)
 
-    def circuit(self, m, threads=1):
-        return OracleCircuit(self, m, threads)
+    def circuit(self, m, threads=1, verifier_only=False):
+        return OracleCircuit(self, m, threads, verifier_only)
 
 
 class OracleMerkle:
@@ -200,9 +200,11 @@ class OracleCircuit:
     INFO = ["degree_bits", "num_constants", "num_gate_constraints", "num_partial_products", "num_public_inputs",
             "num_selectors", "num_fri_rounds", "final_poly_len", "pi_row", "constant_row", "num_arith_ops", "num_poseidon_rows"]
 
-    def __init__(self, o, m, threads=1):
+    def __init__(self, o, m, threads=1, verifier_only=False):
         self.o, self.m = o, m
         lib = o.lib
+        lib.orc_circuit_new_verifier_only.restype = _vp
+        lib.orc_verify_bytes_message.restype = ctypes.c_char_p
         lib.orc_circuit_new.restype = _vp
         lib.orc_witness_new.restype = _vp
         lib.orc_witness_from_matrix.restype = _vp
@@ -213,7 +215,7 @@ class OracleCircuit:
         lib.orc_witness_public_inputs.restype = _sz
         lib.orc_circuit_gate_order.restype = _sz
         lib.orc_verify_message.restype = ctypes.c_char_p
-        self.h = _vp(lib.orc_circuit_new(_sz(m), _u32(threads)))
+        self.h = _vp(lib.orc_circuit_new_verifier_only(_sz(m)) if verifier_only else lib.orc_circuit_new(_sz(m), _u32(threads)))
         info = np.zeros(12, dtype=np.uint64)
         lib.orc_circuit_info(self.h, _p(info))
         self.info = dict(zip(self.INFO, (int(x) for x in info)))
@@ -248,6 +250,13 @@ class OracleCircuit:
 
     def witness(self, a, b, filler_seed=0x504C4F4E4B5932):
         return OracleWitness(self, u64(a).reshape(-1), u64(b).reshape(-1), filler_seed)
+
+    def verify_bytes(self, proof_bytes, constants_sigmas_cap, circuit_digest):
+        """The restated native verifier on raw ProofWithPublicInputs bytes + VerifierOnlyCircuitData."""
+        buf = np.frombuffer(proof_bytes, dtype=np.uint8).copy()
+        cap, dg = u64(constants_sigmas_cap), u64(circuit_digest)
+        r = self.o.lib.orc_verify_bytes(self.h, _p(cap), _p(dg), _p(buf), _sz(buf.size))
+        return r == 0, self.o.lib.orc_verify_bytes_message().decode()
 
     def __del__(self):
         try:
