@@ -190,6 +190,47 @@ int gl_circuit_constants_sigmas_cap(const gl_circuit* c, uint64_t* h_out);     /
 const gl_batch* gl_circuit_constants_sigmas_batch(const gl_circuit* c);
 void gl_circuit_free(gl_circuit* c);
 
+/* ---- prover phases ---------------------------------------------------------------------------------*/
+/* The seam for a caller that keeps the Fiat-Shamir transcript (iop/challenger.rs) on its own side: each entry
+ * point replaces one call of plonk::prover::prove and returns exactly what the transcript absorbs next.
+ * gl_prove() below is these calls in the order of prover.rs:102-329 with the Challenger in C++.
+ * All polynomial-sized data stays in HBM; challenges may be non-canonical u64, outputs are canonical. */
+typedef struct gl_fri gl_fri;
+
+/* all_wires_permutation_partial_products (plonk/prover.rs:189-200,332-416) followed by the commitment of
+ * prover.rs:212-223: d_wires[135][n] witness VALUES on the device -> PolynomialBatch of the 2 Z and 18 partial
+ * product polynomials (column order zs, then partial products, as prover.rs:202-210). */
+int gl_partial_products(gl_ctx* ctx, const gl_circuit* c, const uint64_t* d_wires, const uint64_t betas[2],
+                        const uint64_t gammas[2], gl_batch** out);
+/* compute_quotient_polys + the split into quotient_degree_factor chunks + from_coeffs (plonk/prover.rs:229-271,
+ * 574-744; vanishing_poly.rs:164-330): PolynomialBatch of the 2 x 8 chunk polynomials. */
+int gl_quotient_polys(gl_ctx* ctx, const gl_circuit* c, const gl_batch* wires, const gl_batch* zs_partial_products,
+                      const uint64_t public_inputs_hash[4], const uint64_t betas[2], const uint64_t gammas[2],
+                      const uint64_t alphas[2], gl_batch** out);
+/* OpeningSet::new's eval_commitment (plonk/proof.rs:306-344): polynomials first_col .. first_col + num_cols of a
+ * batch at the extension point z; h_out[num_cols][2]. */
+int gl_open_at(gl_ctx* ctx, const gl_batch* b, const uint64_t z[2], size_t first_col, size_t num_cols, uint64_t* h_out);
+/* PolynomialBatch::prove_openings up to the call of fri_proof (fri/oracle.rs:162-204): batches in oracle order
+ * constants||sigmas, wires, Z||partial products, quotient (circuit_data.rs:586-595); opens everything at zeta and
+ * the Z polynomials at g*zeta, final = alpha^2 Q0 + Q1, LDE onto the coset.  The batches must outlive the gl_fri. */
+int gl_fri_combine(gl_ctx* ctx, const gl_circuit* c, const gl_batch* const batches[4], const uint64_t zeta[2],
+                   const uint64_t alpha[2], gl_fri** out);
+/* fri_committed_trees, one loop iteration in two halves (fri/prover.rs:76-103): Merkle tree of the current
+ * codeword -> its cap h_cap_out[2^cap_height][4]; then, with the beta drawn after observing that cap, the fold. */
+int gl_fri_commit_round(gl_fri* f, uint64_t* h_cap_out);
+int gl_fri_fold(gl_fri* f, const uint64_t beta[2]);
+/* final_poly (fri/prover.rs:106-111): *num_words = 2 * len; h_out (may be null to query the size) = (a, b) pairs */
+int gl_fri_final_poly(gl_fri* f, uint64_t* h_out, size_t cap_words, size_t* num_words);
+/* fri_proof_of_work (fri/prover.rs:115-160): the SMALLEST witness w with
+ * leading_zeros(permute(sponge_state overlaid with input_buffer[0..input_len) and w at input_len)[7]) >= min_leading_zeros */
+int gl_pow_grind(gl_ctx* ctx, const uint64_t sponge_state[12], const uint64_t* input_buffer, uint32_t input_len,
+                 uint32_t min_leading_zeros, uint64_t* witness);
+/* fri_prover_query_rounds (fri/prover.rs:162-216) for the given x_index values (challenge mod lde_size), as the
+ * serialised Vec<FriQueryRound> body (util/serialization/mod.rs:1477-1546).  h_blob may be null to query the size. */
+int gl_fri_query(gl_fri* f, const uint32_t* x_index, uint32_t num_queries, uint8_t* h_blob, size_t cap_bytes,
+                 size_t* num_bytes);
+void gl_fri_free(gl_fri* f);
+
 /* ---- prove() ---------------------------------------------------------------------------------------*/
 /* plonk::prover::prove (plonky2/src/plonk/prover.rs:102-329) from step 4 on, i.e. given the FULL witness matrix
  * `MatrixWitness.wire_values` (iop/witness.rs:256-258) h_wires[num_wires][n] and the public inputs.  Every
@@ -208,6 +249,8 @@ int gl_proof_bytes(const gl_proof* p, uint8_t* h_out, size_t cap);
  * then the FRI betas (2 words each); returns the number of words written */
 size_t gl_proof_challenges(const gl_proof* p, uint64_t* h_out);
 int gl_proof_caps(const gl_proof* p, uint64_t* h_out /* [3][2^cap_height][4]: wires, zs_pp, quotient */);
+/* the next two need gl_ctx_capture_intermediates(ctx, 1) before proving (two extra device->host copies per proof) */
+int gl_ctx_capture_intermediates(gl_ctx* ctx, int enable);
 int gl_proof_zs_partial_products(const gl_proof* p, uint64_t* h_out /* [20][n] values */);
 int gl_proof_quotient_chunks(const gl_proof* p, uint64_t* h_out /* [16][n] coefficients */);
 size_t gl_proof_query_indices(const gl_proof* p, uint64_t* h_out);

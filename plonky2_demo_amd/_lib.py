@@ -91,6 +91,17 @@ SIGNATURES = {
     "gl_circuit_constants_sigmas_cap": (c_int, [c_vp, c_vp]),
     "gl_circuit_constants_sigmas_batch": (c_vp, [c_vp]),
     "gl_circuit_free": (None, [c_vp]),
+    "gl_partial_products": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_vp)]),
+    "gl_quotient_polys": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_vp)]),
+    "gl_open_at": (c_int, [c_vp, c_vp, c_vp, c_sz, c_sz, c_vp]),
+    "gl_fri_combine": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_vp, c_vp, ctypes.POINTER(c_vp)]),
+    "gl_fri_commit_round": (c_int, [c_vp, c_vp]),
+    "gl_fri_fold": (c_int, [c_vp, c_vp]),
+    "gl_fri_final_poly": (c_int, [c_vp, c_vp, c_sz, ctypes.POINTER(c_sz)]),
+    "gl_pow_grind": (c_int, [c_vp, c_vp, c_vp, c_u32, c_u32, c_vp]),
+    "gl_fri_query": (c_int, [c_vp, c_vp, c_u32, c_vp, c_sz, ctypes.POINTER(c_sz)]),
+    "gl_fri_free": (None, [c_vp]),
+    "gl_ctx_capture_intermediates": (c_int, [c_vp, c_int]),
     "gl_prove": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "gl_prove_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "gl_proof_num_bytes": (c_sz, [c_vp]),

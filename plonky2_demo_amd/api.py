@@ -81,6 +81,10 @@ class Context:
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 
+    def capture_intermediates(self, on=True):
+        """Keep each proof's Z / partial-product values and quotient chunks on the host (parity tests)."""
+        check(lib.gl_ctx_capture_intermediates(self.handle, 1 if on else 0))
+
     def timing(self, on=True):
         check(lib.gl_ctx_timing_reset(self.handle))
         check(lib.gl_ctx_timing_enable(self.handle, 1 if on else 0))
@@ -344,9 +348,19 @@ class PolynomialBatch:
         check(lib.gl_batch_prove(self.handle, leaf_index, _p(out), ctypes.byref(n)))
         return out[: n.value].copy()
 
+    handle_owned = True     # False for batches borrowed from a circuit
+
+    def open_at(self, z, first_col=0, num_cols=None, ctx=None):
+        """eval_commitment of OpeningSet::new (plonk/proof.rs:306-344): [num_cols][2] extension values."""
+        num_cols = self.ncols - first_col if num_cols is None else num_cols
+        out = np.empty((num_cols, 2), dtype=np.uint64)
+        check(lib.gl_open_at((ctx or self.ctx).handle, self.handle, _p(_u64(z)), first_col, num_cols, _p(out)))
+        return out
+
     def free(self):
         if self.handle:
-            lib.gl_batch_free(self.handle)
+            if self.handle_owned:
+                lib.gl_batch_free(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -424,6 +438,36 @@ class CircuitData:
         check(lib.gl_circuit_constants_sigmas_cap(self.handle, _p(out)))
         return out
 
+    # ---- prover phases (the seam for a caller that owns the Challenger) ----
+    def _batch(self, handle, ctx):
+        return PolynomialBatch(handle, ctx, self.host.desc.rate_bits, self.host.desc.cap_height)
+
+    @property
+    def constants_sigmas_batch(self):
+        """`prover_data.constants_sigmas_commitment` (borrowed: owned by the circuit)."""
+        b = self._batch(lib.gl_circuit_constants_sigmas_batch(self.handle), self.ctx)
+        b.handle_owned = False
+        return b
+
+    def partial_products(self, d_wires_ptr, betas, gammas, ctx=None):
+        """all_wires_permutation_partial_products + commitment (plonk/prover.rs:189-223)."""
+        ctx = ctx or self.ctx
+        h = ctypes.c_void_p()
+        check(lib.gl_partial_products(ctx.handle, self.handle, d_wires_ptr, _p(_u64(betas)), _p(_u64(gammas)), ctypes.byref(h)))
+        return self._batch(h.value, ctx)
+
+    def quotient_polys(self, wires_batch, zs_batch, public_inputs_hash, betas, gammas, alphas, ctx=None):
+        """compute_quotient_polys + chunking + commitment (plonk/prover.rs:229-271)."""
+        ctx = ctx or self.ctx
+        h = ctypes.c_void_p()
+        check(lib.gl_quotient_polys(ctx.handle, self.handle, wires_batch.handle, zs_batch.handle, _p(_u64(public_inputs_hash)),
+                                    _p(_u64(betas)), _p(_u64(gammas)), _p(_u64(alphas)), ctypes.byref(h)))
+        return self._batch(h.value, ctx)
+
+    def fri(self, batches, zeta, alpha, ctx=None):
+        """PolynomialBatch::prove_openings up to fri_proof (fri/oracle.rs:162-204)."""
+        return FriProver(self, batches, zeta, alpha, ctx or self.ctx)
+
     def prove(self, wires, public_inputs):
         wires, pis = _u64(wires), _u64(public_inputs)
         if wires.shape != (135, self.host.n):
@@ -465,6 +509,59 @@ class CircuitView:
         h = ctypes.c_void_p()
         check(lib.gl_prove(self.ctx.handle, self.cd.handle, _p(wires), _p(pis), pis.size, ctypes.byref(h)))
         return Proof(h.value, self.cd.host.n)
+
+
+class FriProver:
+    """fri_proof (fri/prover.rs:20-66) split at every transcript dependency."""
+
+    def __init__(self, cd, batches, zeta, alpha, ctx):
+        self.ctx, self.cd, self.batches = ctx, cd, list(batches)     # the batches must outlive the FRI state
+        arr = (ctypes.c_void_p * 4)(*[b.handle for b in self.batches])
+        h = ctypes.c_void_p()
+        check(lib.gl_fri_combine(ctx.handle, cd.handle, arr, _p(_u64(zeta)), _p(_u64(alpha)), ctypes.byref(h)))
+        self.handle = h.value
+
+    def commit_round(self):
+        cap = np.empty((1 << self.cd.host.desc.cap_height, 4), dtype=np.uint64)
+        check(lib.gl_fri_commit_round(self.handle, _p(cap)))
+        return cap
+
+    def fold(self, beta):
+        check(lib.gl_fri_fold(self.handle, _p(_u64(beta))))
+
+    def final_poly(self):
+        k = ctypes.c_size_t()
+        check(lib.gl_fri_final_poly(self.handle, None, 0, ctypes.byref(k)))
+        out = np.empty(k.value, dtype=np.uint64)
+        check(lib.gl_fri_final_poly(self.handle, _p(out), out.size, ctypes.byref(k)))
+        return out.reshape(-1, 2)
+
+    def query(self, x_index):
+        xi = np.ascontiguousarray(np.asarray(x_index, dtype=np.uint32))
+        k = ctypes.c_size_t()
+        check(lib.gl_fri_query(self.handle, _p(xi), xi.size, None, 0, ctypes.byref(k)))
+        blob = np.empty(k.value, dtype=np.uint8)
+        check(lib.gl_fri_query(self.handle, _p(xi), xi.size, _p(blob), blob.size, ctypes.byref(k)))
+        return blob.tobytes()
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.gl_fri_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def pow_grind(sponge_state, input_buffer, min_leading_zeros, ctx=None):
+    """fri_proof_of_work (fri/prover.rs:115-160): the smallest valid witness."""
+    ctx = _ctx(ctx)
+    st, buf = _u64(sponge_state), _u64(input_buffer)
+    if st.size != 12:
+        raise ValueError("sponge state has 12 words")
+    w = np.zeros(1, dtype=np.uint64)
+    check(lib.gl_pow_grind(ctx.handle, _p(st), _p(buf) if buf.size else None, buf.size, min_leading_zeros, _p(w)))
+    return int(w[0])
 
 
 class Proof:

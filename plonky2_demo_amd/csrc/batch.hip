@@ -10,11 +10,13 @@
 #include <cstring>
 
 
-static int batch_commit(gl_ctx* c, gl_batch* b, bool is_values) {
-    // values -> coefficients (oracle.rs:51-55), in place on the device copy
-    if (is_values) {
+// `values`: column-major VALUES to interpolate into b->coeffs (may be b->coeffs itself), or null when b->coeffs already
+// holds coefficients
+static int batch_commit(gl_ctx* c, gl_batch* b, const gl_t* values) {
+    // values -> coefficients (oracle.rs:51-55)
+    if (values) {
         c->timing_begin("IFFT");
-        int st = gl_ntt_run(c, b->coeffs, b->n, (uint32_t)b->n, b->coeffs, b->n, b->degree_log, (uint32_t)b->ncols,
+        int st = gl_ntt_run(c, values, b->n, (uint32_t)b->n, b->coeffs, b->n, b->degree_log, (uint32_t)b->ncols,
                             true, 0, 0, gl_host_inverse_2exp(b->degree_log));
         c->timing_end();
         GL_TRY(st);
@@ -59,7 +61,7 @@ static int batch_from_host(gl_ctx* c, const uint64_t* const* h_cols, size_t ncol
         if (e != hipSuccess) { gl_batch_free(b); return gl_fail(GL_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__); }
     }
     GL_CHECK_HIP(hipStreamSynchronize(c->stream));   // caller-owned pageable columns
-    int st = batch_commit(c, b, is_values);
+    int st = batch_commit(c, b, is_values ? b->coeffs : nullptr);
     if (st != GL_OK) { gl_batch_free(b); return st; }
     *out = b;
     return GL_OK;
@@ -78,9 +80,11 @@ extern "C" int gl_batch_from_device(gl_ctx* c, const uint64_t* d_cols, size_t nc
     GL_REQUIRE(d_cols, GL_ERR_ARG, "PolynomialBatch: null device columns");
     gl_batch* b = nullptr;
     GL_TRY(batch_alloc(c, ncols, n, rate_bits, cap_height, &b));
-    hipError_t e = hipMemcpyAsync(b->coeffs, d_cols, ncols * n * sizeof(gl_t), hipMemcpyDeviceToDevice, c->stream);
-    if (e != hipSuccess) { gl_batch_free(b); return gl_fail(GL_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__); }
-    int st = batch_commit(c, b, is_values != 0);
+    if (!is_values) {      // coefficients are kept: copy; values are interpolated straight out of the caller's matrix (left untouched)
+        hipError_t e = hipMemcpyAsync(b->coeffs, d_cols, ncols * n * sizeof(gl_t), hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) { gl_batch_free(b); return gl_fail(GL_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__); }
+    }
+    int st = batch_commit(c, b, is_values ? (const gl_t*)d_cols : nullptr);
     if (st != GL_OK) { gl_batch_free(b); return st; }
     *out = b;
     return GL_OK;

@@ -82,6 +82,9 @@ struct gl_ctx {
     void pool_release(void* p);
     void pool_trim();
 
+    // parity tests: keep the Z / partial-product values and the quotient chunks of each proof on the host
+    bool capture_intermediates = false;
+
     int activate();
     int ensure_scratch(size_t elems);
     int ensure_pinned(size_t bytes);

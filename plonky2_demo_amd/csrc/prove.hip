@@ -163,157 +163,164 @@ static int h2d_async(gl_ctx* c, void* dst, const void* src, size_t bytes) {
     return GL_OK;
 }
 
-static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, bool wires_on_device, const uint64_t* h_pis, size_t npis, gl_proof** out);
-extern "C" int gl_prove(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, const uint64_t* h_pis, size_t npis, gl_proof** out) {
-    return prove_impl(ctx, cir, h_wires, false, h_pis, npis, out);
-}
-extern "C" int gl_prove_device(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t* h_pis, size_t npis, gl_proof** out) {
-    return prove_impl(ctx, cir, d_wires, true, h_pis, npis, out);
-}
-static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, bool wires_on_device, const uint64_t* h_pis, size_t npis, gl_proof** out) {
-    GL_REQUIRE(ctx && cir && h_wires && h_pis && out, GL_ERR_ARG, "gl_prove: null argument");
-    // circuit data is read-only while proving: any context (stream) of the same device may prove against it
-    GL_REQUIRE(cir->ctx->device == ctx->device, GL_ERR_ARG, "gl_prove: circuit lives on another device");
+// ======================================================================================================================
+// Phase-level entry points: the seam of SURVEY 8(b).  A caller that keeps the Fiat-Shamir transcript on its side (the
+// reference's Challenger in Rust) drives these one by one; gl_prove() below is exactly that driver with the transcript
+// in C++.  Every phase leaves its polynomials in HBM and hands back only what the transcript needs.
+// ======================================================================================================================
+
+// ---- 6. all_wires_permutation_partial_products (plonk/prover.rs:332-416): d_zs[20][n] VALUES ----
+static int partial_products_values(gl_ctx* ctx, const gl_circuit* cir, const gl_t* d_wires, const gl_t* betas, const gl_t* gammas, gl_t* d_zs) {
     const gl_circuit_desc& d = cir->desc;
-    GL_REQUIRE(npis == d.num_public_inputs, GL_ERR_ARG, "gl_prove: wrong number of public inputs");
-    GL_TRY(ctx->activate());
-    const size_t n = cir->n, N = n << d.rate_bits;
-    const uint32_t lgn = d.degree_bits, lgN = lgn + d.rate_bits, ncap = 4u << d.cap_height;
+    const size_t n = cir->n;
     hipStream_t st = ctx->stream;
-    std::unique_ptr<gl_proof> proof(new gl_proof());
-    // small host tables uploaded with async copies stay alive until the function returns (after the last sync)
-    std::vector<gl_t> h_apow_quot, h_apow_fri;
-    std::vector<const gl_t*> h_cols;
-
-    // ---- 4. wires commitment (prover.rs:145-156) ----
-    DevBuf d_wit(ctx); GL_TRY(d_wit.alloc(135 * n * sizeof(gl_t)));
-    ctx->timing_begin("H2D witness");
-    GL_CHECK_HIP(hipMemcpyAsync(d_wit.p, h_wires, 135 * n * sizeof(gl_t), wires_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    DevBuf d_chunk(ctx), d_rowp(ctx), d_seg(ctx);
+    const uint32_t nseg = (uint32_t)((n + GLP_SEG - 1) / GLP_SEG);
+    GL_TRY(d_chunk.alloc(2 * GLP_CHUNKS * n * sizeof(gl_t)));
+    GL_TRY(d_rowp.alloc(2 * n * sizeof(gl_t)));
+    GL_TRY(d_seg.alloc(2 * (size_t)nseg * sizeof(gl_t)));
+    GlPowTable xt;
+    GL_TRY(ctx->get_pow_table(gl_host_root_of_unity(d.degree_bits), 1, (uint32_t)((n + 2047) >> 11), &xt));
+    GlPermParams pp;
+    pp.wires = d_wires; pp.sigmas = cir->d_sigmas; pp.xpow_lo = xt.lo; pp.xpow_hi = xt.hi;
+    for (int j = 0; j < 80; j++) pp.k_is[j] = d.k_is[j];
+    for (int i = 0; i < 2; i++) { pp.betas[i] = gl_canon(betas[i]); pp.gammas[i] = gl_canon(gammas[i]); }
+    pp.n = (uint32_t)n; pp.chunk_prod = d_chunk.as<gl_t>(); pp.row_prod = d_rowp.as<gl_t>();
+    ctx->timing_begin("compute partial products");
+    hipLaunchKernelGGL(k_pp_chunk_products, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pp);
+    hipLaunchKernelGGL(k_z_segment_products, dim3(nseg, 2), dim3(256), 0, st, d_rowp.as<gl_t>(), (uint32_t)n, d_seg.as<gl_t>());
+    hipLaunchKernelGGL(k_z_segment_scan, dim3(1), dim3(64), 0, st, d_seg.as<gl_t>(), nseg);
+    hipLaunchKernelGGL(k_z_finalize, dim3(nseg, 2), dim3(256), 0, st, d_rowp.as<gl_t>(), d_chunk.as<gl_t>(), d_seg.as<gl_t>(), (uint32_t)n, d_zs);
     ctx->timing_end();
-    BatchHolder wires; GL_TRY(gl_batch_from_device(ctx, d_wit.as<uint64_t>(), 135, n, d.rate_bits, d.cap_height, 1, &wires.b));
-    // public_inputs_hash (prover.rs:126-127) on the host while the GPU commits
-    gl_t pi_hash[4];
-    glhost::host_hash_no_pad(h_pis, npis, pi_hash);
-    HostChallenger ch;
-    ch.observe_many(cir->circuit_digest, 4);
-    ch.observe_many(pi_hash, 4);
-    std::vector<gl_t> cap(ncap);
-    GL_TRY(gl_batch_cap(wires.b, cap.data()));
-    proof->caps.insert(proof->caps.end(), cap.begin(), cap.end());
-    ch.observe_many(cap.data(), ncap);
-    gl_t betas[2], gammas[2], alphas[2];
-    for (int i = 0; i < 2; i++) betas[i] = ch.challenge();
-    for (int i = 0; i < 2; i++) gammas[i] = ch.challenge();
+    GL_CHECK_HIP(hipGetLastError());
+    return GL_OK;
+}
+static int check_phase_args(gl_ctx* ctx, const gl_circuit* cir) {
+    GL_REQUIRE(ctx && cir, GL_ERR_ARG, "null context / circuit");
+    GL_REQUIRE(cir->ctx->device == ctx->device, GL_ERR_ARG, "circuit lives on another device");
+    return ctx->activate();
+}
+static int check_batch(const gl_circuit* cir, const gl_batch* b, size_t ncols, const char* what) {
+    GL_REQUIRE(b && b->ncols == ncols && b->n == cir->n && b->rate_bits == cir->desc.rate_bits && b->cap_height == cir->desc.cap_height, GL_ERR_ARG, what);
+    return GL_OK;
+}
+extern "C" int gl_partial_products(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t betas[2], const uint64_t gammas[2], gl_batch** out) {
+    GL_TRY(check_phase_args(ctx, cir));
+    GL_REQUIRE(d_wires && betas && gammas && out, GL_ERR_ARG, "gl_partial_products: null argument");
+    DevBuf d_zs(ctx); GL_TRY(d_zs.alloc(20 * cir->n * sizeof(gl_t)));
+    GL_TRY(partial_products_values(ctx, cir, d_wires, betas, gammas, d_zs.as<gl_t>()));
+    return gl_batch_from_device(ctx, d_zs.as<uint64_t>(), 20, cir->n, cir->desc.rate_bits, cir->desc.cap_height, 1, out);
+}
 
-    // ---- 6/7. partial products and Z, commitment (prover.rs:189-223) ----
-    DevBuf d_zs(ctx); GL_TRY(d_zs.alloc(20 * n * sizeof(gl_t)));
-    {
-        DevBuf d_chunk(ctx), d_rowp(ctx), d_seg(ctx);
-        const uint32_t nseg = (uint32_t)((n + GLP_SEG - 1) / GLP_SEG);
-        GL_TRY(d_chunk.alloc(2 * GLP_CHUNKS * n * sizeof(gl_t)));
-        GL_TRY(d_rowp.alloc(2 * n * sizeof(gl_t)));
-        GL_TRY(d_seg.alloc(2 * (size_t)nseg * sizeof(gl_t)));
-        GlPowTable xt;
-        GL_TRY(ctx->get_pow_table(gl_host_root_of_unity(lgn), 1, (uint32_t)((n + 2047) >> 11), &xt));
-        GlPermParams pp;
-        pp.wires = d_wit.as<gl_t>(); pp.sigmas = cir->d_sigmas; pp.xpow_lo = xt.lo; pp.xpow_hi = xt.hi;
-        for (int j = 0; j < 80; j++) pp.k_is[j] = d.k_is[j];
-        for (int i = 0; i < 2; i++) { pp.betas[i] = betas[i]; pp.gammas[i] = gammas[i]; }
-        pp.n = (uint32_t)n; pp.chunk_prod = d_chunk.as<gl_t>(); pp.row_prod = d_rowp.as<gl_t>();
-        ctx->timing_begin("compute partial products");
-        hipLaunchKernelGGL(k_pp_chunk_products, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pp);
-        hipLaunchKernelGGL(k_z_segment_products, dim3(nseg, 2), dim3(256), 0, st, d_rowp.as<gl_t>(), (uint32_t)n, d_seg.as<gl_t>());
-        hipLaunchKernelGGL(k_z_segment_scan, dim3(1), dim3(64), 0, st, d_seg.as<gl_t>(), nseg);
-        hipLaunchKernelGGL(k_z_finalize, dim3(nseg, 2), dim3(256), 0, st, d_rowp.as<gl_t>(), d_chunk.as<gl_t>(), d_seg.as<gl_t>(), (uint32_t)n, d_zs.as<gl_t>());
-        ctx->timing_end();
-        GL_CHECK_HIP(hipGetLastError());
+// ---- 9. compute_quotient_polys + split (plonk/prover.rs:229-258,574-744): d_q[2][8n] -> the 16 chunk COEFFICIENT columns ----
+static int quotient_chunks(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* wires, const gl_batch* zs, const gl_t* pi_hash,
+                           const gl_t* betas, const gl_t* gammas, const gl_t* alphas, gl_t* d_q, std::vector<gl_t>& apow) {
+    const gl_circuit_desc& d = cir->desc;
+    const size_t n = cir->n, N = n << d.rate_bits;
+    const uint32_t lgn = d.degree_bits, lgN = lgn + d.rate_bits;
+    hipStream_t st = ctx->stream;
+    apow.assign(2 * GLQ_MAX_TERMS, 0);
+    for (int b = 0; b < 2; b++) { gl_t x = 1; const gl_t al = gl_canon(alphas[b]); for (int t = 0; t < GLQ_MAX_TERMS; t++) { apow[b * GLQ_MAX_TERMS + t] = x; x = gl_canon(gl_mul(x, al)); } }
+    GL_TRY(ctx->ensure_dev_small(1 << 20));
+    gl_t* d_apow = ctx->dev_small;
+    GL_TRY(h2d_async(ctx, d_apow, apow.data(), apow.size() * sizeof(gl_t)));
+    GlPowTable xt;
+    GL_TRY(ctx->get_pow_table(gl_host_root_of_unity(lgN), GL_MULT_GENERATOR, (uint32_t)((N + 2047) >> 11), &xt));
+    GlQuotParams q;
+    ::memset((void*)&q, 0, sizeof q);
+    q.cs = cir->cs_batch->lde; q.wires = wires->lde; q.zs = zs->lde; q.xpow_lo = xt.lo; q.xpow_hi = xt.hi;
+    q.alpha_pows = d_apow; q.out = d_q;
+    for (int j = 0; j < 80; j++) q.k_is[j] = d.k_is[j];
+    for (int i = 0; i < 2; i++) { q.betas[i] = gl_canon(betas[i]); q.gammas[i] = gl_canon(gammas[i]); }
+    for (int i = 0; i < 4; i++) q.pi_hash[i] = gl_canon(pi_hash[i]);
+    {   // ZeroPolyOnCoset (field/src/zero_poly_coset.rs:19-36)
+        gl_t g_pow_n = GL_MULT_GENERATOR; for (uint32_t i = 0; i < lgn; i++) g_pow_n = gl_sqr(g_pow_n);
+        gl_t w8 = gl_host_root_of_unity(d.rate_bits), x = 1;
+        for (int i = 0; i < 8; i++) { q.zh_evals[i] = gl_canon(gl_sub(gl_mul(g_pow_n, x), 1)); q.zh_inv[i] = gl_canon(gl_inv(q.zh_evals[i])); x = gl_mul(x, w8); }
     }
-    proof->zs_pp.resize(20 * n);
-    GL_TRY(d2h(ctx, proof->zs_pp.data(), d_zs.p, 20 * n * sizeof(gl_t)));
-    BatchHolder zs; GL_TRY(gl_batch_from_device(ctx, d_zs.as<uint64_t>(), 20, n, d.rate_bits, d.cap_height, 1, &zs.b));
-    GL_TRY(gl_batch_cap(zs.b, cap.data()));
-    proof->caps.insert(proof->caps.end(), cap.begin(), cap.end());
-    ch.observe_many(cap.data(), ncap);
-    for (int i = 0; i < 2; i++) alphas[i] = ch.challenge();
-
-    // ---- 9/10. quotient polynomials (prover.rs:229-271) ----
+    q.n_field = (gl_t)n; q.lgN = lgN; q.num_constants = d.num_constants; q.num_selectors = d.num_selectors; q.num_gates = d.num_gates;
+    q.next_step = 1u << d.rate_bits;
+    for (unsigned g = 0; g < d.num_gates; g++) { q.gate_types[g] = d.gate_types[g]; q.gate_sel[g] = d.gate_selector_index[g]; q.group_start[g] = d.gate_group_start[g]; q.group_end[g] = d.gate_group_end[g]; }
+    ctx->timing_begin("compute quotient polys");
+    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
+    ctx->timing_end();
+    GL_CHECK_HIP(hipGetLastError());
+    // coset_ifft(7) of each quotient (prover.rs:739-743); the 8n coefficients ARE the 8 chunks of n (prover.rs:245-258)
+    return gl_ntt_run(ctx, d_q, N, (uint32_t)N, d_q, N, lgN, 2, true, 0, gl_canon(gl_inv(GL_MULT_GENERATOR)), gl_host_inverse_2exp(lgN));
+}
+extern "C" int gl_quotient_polys(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* wires, const gl_batch* zs_partial_products, const uint64_t pi_hash[4],
+                                 const uint64_t betas[2], const uint64_t gammas[2], const uint64_t alphas[2], gl_batch** out) {
+    GL_TRY(check_phase_args(ctx, cir));
+    GL_REQUIRE(pi_hash && betas && gammas && alphas && out, GL_ERR_ARG, "gl_quotient_polys: null argument");
+    GL_TRY(check_batch(cir, wires, 135, "gl_quotient_polys: wires batch does not match the circuit"));
+    GL_TRY(check_batch(cir, zs_partial_products, 20, "gl_quotient_polys: Z / partial-products batch does not match the circuit"));
+    const size_t N = cir->n << cir->desc.rate_bits;
     DevBuf d_q(ctx); GL_TRY(d_q.alloc(2 * N * sizeof(gl_t)));
-    {
-        std::vector<gl_t>& apow = h_apow_quot; apow.assign(2 * GLQ_MAX_TERMS, 0);
-        for (int b = 0; b < 2; b++) { gl_t x = 1; for (int t = 0; t < GLQ_MAX_TERMS; t++) { apow[b * GLQ_MAX_TERMS + t] = x; x = gl_canon(gl_mul(x, alphas[b])); } }
-        GL_TRY(ctx->ensure_dev_small(1 << 20));
-        gl_t* d_apow = ctx->dev_small;
-        GL_TRY(h2d_async(ctx, d_apow, apow.data(), apow.size() * sizeof(gl_t)));
-        GlPowTable xt;
-        GL_TRY(ctx->get_pow_table(gl_host_root_of_unity(lgN), GL_MULT_GENERATOR, (uint32_t)((N + 2047) >> 11), &xt));
-        GlQuotParams q;
-        ::memset((void*)&q, 0, sizeof q);
-        q.cs = cir->cs_batch->lde; q.wires = wires.b->lde; q.zs = zs.b->lde; q.xpow_lo = xt.lo; q.xpow_hi = xt.hi;
-        q.alpha_pows = d_apow; q.out = d_q.as<gl_t>();
-        for (int j = 0; j < 80; j++) q.k_is[j] = d.k_is[j];
-        for (int i = 0; i < 2; i++) { q.betas[i] = betas[i]; q.gammas[i] = gammas[i]; }
-        for (int i = 0; i < 4; i++) q.pi_hash[i] = pi_hash[i];
-        {   // ZeroPolyOnCoset (field/src/zero_poly_coset.rs:19-36)
-            gl_t g_pow_n = GL_MULT_GENERATOR; for (uint32_t i = 0; i < lgn; i++) g_pow_n = gl_sqr(g_pow_n);
-            gl_t w8 = gl_host_root_of_unity(d.rate_bits), x = 1;
-            for (int i = 0; i < 8; i++) { q.zh_evals[i] = gl_canon(gl_sub(gl_mul(g_pow_n, x), 1)); q.zh_inv[i] = gl_canon(gl_inv(q.zh_evals[i])); x = gl_mul(x, w8); }
-        }
-        q.n_field = (gl_t)n; q.lgN = lgN; q.num_constants = d.num_constants; q.num_selectors = d.num_selectors; q.num_gates = d.num_gates;
-        q.next_step = 1u << d.rate_bits;
-        for (unsigned g = 0; g < d.num_gates; g++) { q.gate_types[g] = d.gate_types[g]; q.gate_sel[g] = d.gate_selector_index[g]; q.group_start[g] = d.gate_group_start[g]; q.group_end[g] = d.gate_group_end[g]; }
-        ctx->timing_begin("compute quotient polys");
-        hipLaunchKernelGGL(k_quotient, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
-        ctx->timing_end();
-        GL_CHECK_HIP(hipGetLastError());
-        // coset_ifft(7) of each quotient (prover.rs:739-743); the 8n coefficients ARE the 8 chunks of n (prover.rs:245-258)
-        GL_TRY(gl_ntt_run(ctx, d_q.as<gl_t>(), N, (uint32_t)N, d_q.as<gl_t>(), N, lgN, 2, true, 0, gl_canon(gl_inv(GL_MULT_GENERATOR)), gl_host_inverse_2exp(lgN)));
-    }
-    proof->quotient.resize(16 * n);
-    GL_TRY(d2h(ctx, proof->quotient.data(), d_q.p, 16 * n * sizeof(gl_t)));
-    BatchHolder quot; GL_TRY(gl_batch_from_device(ctx, d_q.as<uint64_t>(), 16, n, d.rate_bits, d.cap_height, 0, &quot.b));
-    GL_TRY(gl_batch_cap(quot.b, cap.data()));
-    proof->caps.insert(proof->caps.end(), cap.begin(), cap.end());
-    ch.observe_many(cap.data(), ncap);
+    std::vector<gl_t> apow;
+    GL_TRY(quotient_chunks(ctx, cir, wires, zs_partial_products, pi_hash, betas, gammas, alphas, d_q.as<gl_t>(), apow));
+    int rc = gl_batch_from_device(ctx, d_q.as<uint64_t>(), 16, cir->n, cir->desc.rate_bits, cir->desc.cap_height, 0, out);
+    GL_CHECK_HIP(hipStreamSynchronize(ctx->stream));      // `apow` was the source of an async upload
+    return rc;
+}
 
-    // ---- 11. zeta (prover.rs:273-283) ----
-    gl2_t zeta; zeta.a = ch.challenge(); zeta.b = ch.challenge();
-    {
-        gl2_t zn = zeta;
-        for (uint32_t i = 0; i < lgn; i++) zn = gl2_mul(zn, zn);
-        zn = gl2_canon(zn);
-        if (zn.a == 1 && zn.b == 0) return gl_fail(GL_ERR_ZETA_IN_SUBGROUP, "Opening point is in the subgroup.", __FILE__, __LINE__);
-    }
-    const gl_t g = gl_host_root_of_unity(lgn);
-    const gl2_t gzeta = gl2_canon(gl2_scalar(zeta, g));
+// ---- 12. OpeningSet::new (plonk/proof.rs:306-344): polynomials `first .. first + count` of a batch at an extension point ----
+static void launch_open(gl_ctx* ctx, const gl_batch* b, size_t first, size_t count, gl2_t z, gl_t* d_out) {
+    hipLaunchKernelGGL(k_eval_at_ext, dim3((unsigned)count), dim3(256), 0, ctx->stream, b->coeffs + first * b->n, (uint32_t)b->n, (uint64_t)b->n, z.a, z.b, d_out);
+}
+extern "C" int gl_open_at(gl_ctx* ctx, const gl_batch* b, const uint64_t z[2], size_t first_col, size_t num_cols, uint64_t* h_out) {
+    GL_REQUIRE(ctx && b && z && h_out, GL_ERR_ARG, "gl_open_at: null argument");
+    GL_REQUIRE(first_col <= b->ncols && num_cols <= b->ncols - first_col && num_cols <= 4096, GL_ERR_ARG, "gl_open_at: column range out of bounds");
+    if (!num_cols) return GL_OK;
+    GL_TRY(ctx->activate());
+    GL_TRY(ctx->ensure_dev_small(1 << 20));
+    gl_t* d_open = ctx->dev_small + 4096;
+    ctx->timing_begin("construct the opening set");
+    launch_open(ctx, b, first_col, num_cols, gl2_make(gl_canon(z[0]), gl_canon(z[1])), d_open);
+    ctx->timing_end();
+    GL_CHECK_HIP(hipGetLastError());
+    return d2h(ctx, h_out, d_open, 2 * num_cols * sizeof(gl_t));
+}
 
-    // ---- 12. openings (proof.rs:306-344) ----
-    const gl_batch* oracles[4] = {cir->cs_batch, wires.b, zs.b, quot.b};
+// ---- 14. PolynomialBatch::prove_openings (fri/oracle.rs:162-219) + fri_proof (fri/prover.rs:20-216), split at every
+//          transcript dependency ----
+struct gl_fri {
+    gl_ctx* ctx = nullptr;
+    gl_circuit_desc desc;
+    const gl_batch* oracles[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t n = 0;
+    uint32_t lgN = 0;
+    // commit phase state
+    unsigned round = 0;                      // rounds folded so far
+    bool committed = false;                  // the current round's tree exists and waits for its beta
+    std::unique_ptr<DevBuf> cur_vals;        // value planes [2][2^cur_lgN] of the current codeword
+    std::unique_ptr<DevBuf> coef;            // coefficient planes [2][cur_n]
+    size_t cur_n = 0; uint32_t cur_lgN = 0; gl_t shift = GL_MULT_GENERATOR;
+    std::vector<std::unique_ptr<MerkleHolder>> trees;
+    std::vector<std::unique_ptr<DevBuf>> vals;           // value planes of each committed round (query phase)
+    std::vector<uint32_t> lg;
+    // host sources of asynchronous uploads (alive until the object dies)
+    std::vector<const gl_t*> h_cols; std::vector<gl_t> h_apow;
+};
+extern "C" void gl_fri_free(gl_fri* f) {
+    if (!f) return;
+    if (f->ctx) (void)hipStreamSynchronize(f->ctx->stream);
+    delete f;
+}
+extern "C" int gl_fri_combine(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* const batches[4], const uint64_t zeta_in[2], const uint64_t alpha_in[2], gl_fri** out) {
+    GL_TRY(check_phase_args(ctx, cir));
+    GL_REQUIRE(batches && zeta_in && alpha_in && out, GL_ERR_ARG, "gl_fri_combine: null argument");
+    const gl_circuit_desc& d = cir->desc;
+    const size_t n = cir->n, N = n << d.rate_bits;
     const size_t ncs = d.num_constants + 80, nopen = ncs + 135 + 20 + 16;
-    std::vector<gl_t> open_zeta(2 * nopen), open_next(2 * 2);
-    {
-        GL_TRY(ctx->ensure_dev_small(1 << 20));
-        gl_t* d_open = ctx->dev_small + 4096;
-        size_t off = 0;
-        ctx->timing_begin("construct the opening set");
-        for (int o = 0; o < 4; o++) {
-            hipLaunchKernelGGL(k_eval_at_ext, dim3((unsigned)oracles[o]->ncols), dim3(256), 0, st, oracles[o]->coeffs, (uint32_t)n, (uint64_t)n, zeta.a, zeta.b, d_open + 2 * off);
-            off += oracles[o]->ncols;
-        }
-        hipLaunchKernelGGL(k_eval_at_ext, dim3(2), dim3(256), 0, st, zs.b->coeffs, (uint32_t)n, (uint64_t)n, gzeta.a, gzeta.b, d_open + 2 * nopen);
-        ctx->timing_end();
-        GL_CHECK_HIP(hipGetLastError());
-        std::vector<gl_t> tmp(2 * nopen + 4);
-        GL_TRY(d2h(ctx, tmp.data(), d_open, tmp.size() * sizeof(gl_t)));
-        memcpy(open_zeta.data(), tmp.data(), 2 * nopen * sizeof(gl_t));
-        memcpy(open_next.data(), tmp.data() + 2 * nopen, 4 * sizeof(gl_t));
-    }
-    // FriOpenings order = oracle order: constants, sigmas, wires, zs, partial products, quotient; then zs_next
-    ch.observe_many(open_zeta.data(), open_zeta.size());
-    ch.observe_many(open_next.data(), open_next.size());
-
-    // ---- 14. prove_openings (fri/oracle.rs:162-219) ----
-    gl2_t fri_alpha; fri_alpha.a = ch.challenge(); fri_alpha.b = ch.challenge();
-    DevBuf d_final(ctx);    GL_TRY(d_final.alloc(2 * n * sizeof(gl_t)));            // planes a, b of alpha^2 Q0 + Q1
+    const size_t want[4] = {ncs, 135, 20, 16};
+    for (int o = 0; o < 4; o++) GL_TRY(check_batch(cir, batches[o], want[o], "gl_fri_combine: oracle order is constants||sigmas, wires, Z||partial products, quotient"));
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<gl_fri, void (*)(gl_fri*)> f(new gl_fri(), gl_fri_free);
+    f->ctx = ctx; f->desc = d; f->n = n; f->lgN = d.degree_bits + d.rate_bits;
+    for (int o = 0; o < 4; o++) f->oracles[o] = batches[o];
+    const gl2_t zeta = gl2_make(gl_canon(zeta_in[0]), gl_canon(zeta_in[1])), fri_alpha = gl2_make(gl_canon(alpha_in[0]), gl_canon(alpha_in[1]));
+    const gl2_t gzeta = gl2_canon(gl2_scalar(zeta, gl_host_root_of_unity(d.degree_bits)));
+    f->coef.reset(new DevBuf(ctx)); GL_TRY(f->coef->alloc(2 * n * sizeof(gl_t)));            // planes a, b of alpha^2 Q0 + Q1
     {
         DevBuf d_F(ctx), d_heads(ctx), d_cols(ctx), d_apow(ctx);
         const uint32_t seg_len = (uint32_t)(n / 1024 > 32 ? n / 1024 : (n >= 32 ? 32 : n));      // at most 1024 segments
@@ -322,16 +329,16 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
         GL_TRY(d_heads.alloc(2 * (size_t)nseg * sizeof(gl_t)));
         GL_TRY(d_cols.alloc((nopen + 2) * sizeof(gl_t*)));
         GL_TRY(d_apow.alloc(2 * (nopen + 2) * sizeof(gl_t)));
-        std::vector<const gl_t*>& cols = h_cols;
-        for (int o = 0; o < 4; o++) for (size_t c = 0; c < oracles[o]->ncols; c++) cols.push_back(oracles[o]->coeffs + c * n);
-        cols.push_back(zs.b->coeffs); cols.push_back(zs.b->coeffs + n);
-        std::vector<gl_t>& apow = h_apow_fri; apow.assign(2 * (nopen + 2), 0);
+        std::vector<const gl_t*>& cols = f->h_cols;
+        for (int o = 0; o < 4; o++) for (size_t c = 0; c < batches[o]->ncols; c++) cols.push_back(batches[o]->coeffs + c * n);
+        cols.push_back(batches[2]->coeffs); cols.push_back(batches[2]->coeffs + n);
+        std::vector<gl_t>& apow = f->h_apow; apow.assign(2 * (nopen + 2), 0);
         { gl2_t x = gl2_make(1, 0); for (size_t j = 0; j < nopen; j++) { apow[2 * j] = x.a; apow[2 * j + 1] = x.b; x = gl2_canon(gl2_mul(x, fri_alpha)); } }
         { gl2_t x = gl2_make(1, 0); for (size_t j = 0; j < 2; j++) { apow[2 * (nopen + j)] = x.a; apow[2 * (nopen + j) + 1] = x.b; x = gl2_canon(gl2_mul(x, fri_alpha)); } }
         GL_TRY(h2d_async(ctx, d_cols.p, cols.data(), cols.size() * sizeof(gl_t*)));
         GL_TRY(h2d_async(ctx, d_apow.p, apow.data(), apow.size() * sizeof(gl_t)));
         gl_t* Fa = d_F.as<gl_t>(); gl_t* Fb = Fa + n;
-        gl_t* Qa = d_final.as<gl_t>(); gl_t* Qb = Qa + n;
+        gl_t* Qa = f->coef->as<gl_t>(); gl_t* Qb = Qa + n;
         const gl2_t shift = gl2_canon(gl2_mul(fri_alpha, fri_alpha));     // alpha^(#polys of batch 1) (reducing.rs:103-106)
         const unsigned gb = (unsigned)((n + 255) / 256), sb = (nseg + 63) / 64;
         ctx->timing_begin("reduce batch + divide by linear");
@@ -349,108 +356,127 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
         GL_CHECK_HIP(hipGetLastError());
     }
     // final_poly.lde(rate_bits).coset_fft(7) on both planes (fri/oracle.rs:199-204)
-    DevBuf d_vals(ctx); GL_TRY(d_vals.alloc(2 * N * sizeof(gl_t)));
-    GL_TRY(gl_ntt_run(ctx, d_final.as<gl_t>(), n, (uint32_t)n, d_vals.as<gl_t>(), N, lgN, 2, false, GL_MULT_GENERATOR, 0, 1));
+    f->cur_vals.reset(new DevBuf(ctx)); GL_TRY(f->cur_vals->alloc(2 * N * sizeof(gl_t)));
+    GL_TRY(gl_ntt_run(ctx, f->coef->as<gl_t>(), n, (uint32_t)n, f->cur_vals->as<gl_t>(), N, f->lgN, 2, false, GL_MULT_GENERATOR, 0, 1));
+    f->cur_n = n; f->cur_lgN = f->lgN;
+    *out = f.release();
+    return GL_OK;
+}
+// fri_committed_trees, first half of one loop iteration (fri/prover.rs:76-92): Merkle tree of the current codeword
+extern "C" int gl_fri_commit_round(gl_fri* f, uint64_t* h_cap_out) {
+    GL_REQUIRE(f && h_cap_out, GL_ERR_ARG, "gl_fri_commit_round: null argument");
+    GL_REQUIRE(f->round < f->desc.num_fri_rounds && !f->committed, GL_ERR_ARG, "gl_fri_commit_round: no round left to commit (call gl_fri_fold first)");
+    gl_ctx* ctx = f->ctx;
+    GL_TRY(ctx->activate());
+    const uint32_t ab = f->desc.fri_arity_bits[f->round], arity = 1u << ab;
+    const size_t curN = size_t(1) << f->cur_lgN;
+    // leaves: `arity` consecutive entries of the bit-reversed value array, flattened (fri/prover.rs:80-89)
+    std::vector<uint64_t> offs(2 * arity);
+    for (uint32_t k = 0; k < arity; k++)
+        for (uint32_t cpt = 0; cpt < 2; cpt++) offs[2 * k + cpt] = (uint64_t)cpt * curN + (uint64_t)host_bitrev32(k, ab) * (curN >> ab);
+    std::unique_ptr<MerkleHolder> tree(new MerkleHolder(ctx));
+    GL_TRY(gl_merkle_build(ctx, f->cur_vals->as<gl_t>(), offs.data(), 2 * arity, f->cur_lgN - ab, f->desc.cap_height, &tree->m));
+    GL_TRY(d2h(ctx, h_cap_out, tree->m.level_ptr(tree->m.num_levels() - 1), (size_t(4) << f->desc.cap_height) * sizeof(gl_t)));
+    f->trees.push_back(std::move(tree));
+    f->committed = true;
+    return GL_OK;
+}
+// second half (fri/prover.rs:94-103): fold the coefficients by beta, next codeword on the coset shift^arity
+extern "C" int gl_fri_fold(gl_fri* f, const uint64_t beta_in[2]) {
+    GL_REQUIRE(f && beta_in, GL_ERR_ARG, "gl_fri_fold: null argument");
+    GL_REQUIRE(f->committed, GL_ERR_ARG, "gl_fri_fold: commit the round first");
+    gl_ctx* ctx = f->ctx;
+    GL_TRY(ctx->activate());
+    const uint32_t ab = f->desc.fri_arity_bits[f->round], arity = 1u << ab;
+    const gl2_t beta = gl2_make(gl_canon(beta_in[0]), gl_canon(beta_in[1]));
+    const size_t next_n = f->cur_n >> ab;
+    GL_REQUIRE(next_n >= 1, GL_ERR_INTERNAL, "FRI fold below one coefficient");
+    std::unique_ptr<DevBuf> next(new DevBuf(ctx));
+    GL_TRY(next->alloc(2 * next_n * sizeof(gl_t)));
+    ctx->timing_begin("fold codewords in the commitment phase");
+    hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((next_n + 255) / 256)), dim3(256), 0, ctx->stream, f->coef->as<gl_t>(), f->coef->as<gl_t>() + f->cur_n,
+                       (uint32_t)next_n, arity, beta.a, beta.b, next->as<gl_t>(), next->as<gl_t>() + next_n);
+    ctx->timing_end();
+    GL_CHECK_HIP(hipGetLastError());
+    f->shift = gl_canon(gl_exp(f->shift, arity));
+    f->vals.push_back(std::move(f->cur_vals)); f->lg.push_back(f->cur_lgN);
+    f->cur_lgN -= ab;
+    f->cur_vals.reset(new DevBuf(ctx));
+    GL_TRY(f->cur_vals->alloc(2 * (size_t(1) << f->cur_lgN) * sizeof(gl_t)));
+    GL_TRY(gl_ntt_run(ctx, next->as<gl_t>(), next_n, (uint32_t)next_n, f->cur_vals->as<gl_t>(), size_t(1) << f->cur_lgN, f->cur_lgN, 2, false, f->shift, 0, 1));
+    f->coef = std::move(next);
+    f->cur_n = next_n;
+    f->round++; f->committed = false;
+    return GL_OK;
+}
+// final polynomial: the remaining non-zero coefficients (coeffs.truncate(len >> rate_bits), fri/prover.rs:106-111), interleaved (a, b)
+extern "C" int gl_fri_final_poly(gl_fri* f, uint64_t* h_out, size_t cap_words, size_t* num_words) {
+    GL_REQUIRE(f && num_words, GL_ERR_ARG, "gl_fri_final_poly: null argument");
+    GL_REQUIRE(f->round == f->desc.num_fri_rounds && !f->committed, GL_ERR_ARG, "gl_fri_final_poly: reduction rounds not finished");
+    *num_words = 2 * f->cur_n;
+    if (!h_out) return GL_OK;
+    GL_REQUIRE(cap_words >= 2 * f->cur_n, GL_ERR_ARG, "gl_fri_final_poly: output too small");
+    GL_TRY(f->ctx->activate());
+    std::vector<gl_t> fin(2 * f->cur_n);
+    GL_TRY(d2h(f->ctx, fin.data(), f->coef->p, 2 * f->cur_n * sizeof(gl_t)));
+    for (size_t i = 0; i < f->cur_n; i++) { h_out[2 * i] = fin[i]; h_out[2 * i + 1] = fin[f->cur_n + i]; }
+    return GL_OK;
+}
 
-    // ---- fri_committed_trees (fri/prover.rs:69-112) ----
-    std::vector<std::unique_ptr<MerkleHolder>> fri_trees;
-    std::vector<std::unique_ptr<DevBuf>> fri_vals;          // value planes of each round (kept for the query phase)
-    std::vector<uint32_t> fri_lg;                           // log2 of each round's value length
-    std::vector<gl_t> fri_caps, fri_betas;
-    std::unique_ptr<DevBuf> cur_vals(new DevBuf(ctx));
-    cur_vals->p = d_vals.p; d_vals.p = nullptr;
-    DevBuf coef_a(ctx), coef_b(ctx);                        // ping-pong coefficient planes [2][cur_n]
-    coef_a.p = d_final.p; d_final.p = nullptr;
-    size_t cur_n = n;                                       // non-zero coefficients
-    uint32_t cur_lgN = lgN;
-    gl_t shift = GL_MULT_GENERATOR;
-    for (unsigned r = 0; r < d.num_fri_rounds; r++) {
-        const uint32_t ab = d.fri_arity_bits[r], arity = 1u << ab;
-        const size_t curN = size_t(1) << cur_lgN;
-        // leaves: `arity` consecutive entries of the bit-reversed value array, flattened (fri/prover.rs:80-89)
-        std::vector<uint64_t> offs(2 * arity);
-        for (uint32_t k = 0; k < arity; k++)
-            for (uint32_t cpt = 0; cpt < 2; cpt++) offs[2 * k + cpt] = (uint64_t)cpt * curN + (uint64_t)host_bitrev32(k, ab) * (curN >> ab);
-        std::unique_ptr<MerkleHolder> tree(new MerkleHolder(ctx));
-        GL_TRY(gl_merkle_build(ctx, cur_vals->as<gl_t>(), offs.data(), 2 * arity, cur_lgN - ab, d.cap_height, &tree->m));
-        GL_TRY(d2h(ctx, cap.data(), tree->m.level_ptr(tree->m.num_levels() - 1), ncap * sizeof(gl_t)));
-        fri_caps.insert(fri_caps.end(), cap.begin(), cap.end());
-        ch.observe_many(cap.data(), ncap);
-        gl2_t beta; beta.a = ch.challenge(); beta.b = ch.challenge();
-        fri_betas.push_back(beta.a); fri_betas.push_back(beta.b);
-        // fold the coefficients (fri/prover.rs:94-103)
-        const size_t next_n = cur_n >> ab;
-        GL_REQUIRE(next_n >= 1, GL_ERR_INTERNAL, "FRI fold below one coefficient");
-        GL_TRY(coef_b.alloc(2 * next_n * sizeof(gl_t)));
-        ctx->timing_begin("fold codewords in the commitment phase");
-        hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((next_n + 255) / 256)), dim3(256), 0, st, coef_a.as<gl_t>(), coef_a.as<gl_t>() + cur_n,
-                           (uint32_t)next_n, arity, beta.a, beta.b, coef_b.as<gl_t>(), coef_b.as<gl_t>() + next_n);
-        ctx->timing_end();
+// ---- fri_proof_of_work (fri/prover.rs:115-160): smallest w such that permute(state with the pending inputs and w)[7] has
+//      enough leading zeros.  `sponge_state` is the Challenger's sponge, `input_buffer[0..input_len)` its pending inputs. ----
+extern "C" int gl_pow_grind(gl_ctx* ctx, const uint64_t sponge_state[12], const uint64_t* input_buffer, uint32_t input_len, uint32_t min_leading_zeros, uint64_t* witness) {
+    GL_REQUIRE(ctx && sponge_state && witness && (input_buffer || !input_len), GL_ERR_ARG, "gl_pow_grind: null argument");
+    GL_REQUIRE(input_len < 8 && min_leading_zeros <= 40, GL_ERR_ARG, "gl_pow_grind: the witness must fit the rate (input_len < 8), at most 40 bits of work");
+    GL_TRY(ctx->activate());
+    hipStream_t st = ctx->stream;
+    GL_TRY(ctx->ensure_dev_small(1 << 20));
+    unsigned long long* d_res = (unsigned long long*)ctx->dev_small;
+    GlPowParams pw;
+    for (int i = 0; i < 12; i++) pw.state[i] = sponge_state[i];
+    for (uint32_t i = 0; i < input_len; i++) pw.state[i] = input_buffer[i];
+    pw.pos = input_len; pw.min_leading_zeros = min_leading_zeros; pw.result = d_res;
+    // expected 2^pow_bits candidates: scan ascending windows of 2 * 2^pow_bits (86 % hit rate each) so that little work
+    // is wasted; the window's atomicMin keeps the result the global minimum
+    const uint64_t batch = uint64_t(2) << min_leading_zeros;
+    unsigned long long res = ~0ull;
+    ctx->timing_begin("find proof-of-work witness");
+    for (uint64_t base = 0; base < GL_P; base += batch) {
+        GL_CHECK_HIP(hipMemsetAsync(d_res, 0xFF, sizeof(unsigned long long), st));
+        pw.base = base; pw.count = (GL_P - base < batch) ? GL_P - base : batch;
+        hipLaunchKernelGGL(k_pow_grind, dim3((unsigned)((pw.count + 255) / 256)), dim3(256), 0, st, pw);
         GL_CHECK_HIP(hipGetLastError());
-        shift = gl_canon(gl_exp(shift, arity));
-        fri_trees.push_back(std::move(tree)); fri_vals.push_back(std::move(cur_vals)); fri_lg.push_back(cur_lgN);
-        cur_lgN -= ab;
-        cur_vals.reset(new DevBuf(ctx));
-        GL_TRY(cur_vals->alloc(2 * (size_t(1) << cur_lgN) * sizeof(gl_t)));
-        GL_TRY(gl_ntt_run(ctx, coef_b.as<gl_t>(), next_n, (uint32_t)next_n, cur_vals->as<gl_t>(), size_t(1) << cur_lgN, cur_lgN, 2, false, shift, 0, 1));
-        std::swap(coef_a.p, coef_b.p);
-        coef_b.release();
-        cur_n = next_n;
+        GL_TRY(d2h(ctx, &res, d_res, sizeof res));
+        if (res != ~0ull) break;
     }
-    // final polynomial: the remaining non-zero coefficients (coeffs.truncate(len >> rate_bits), fri/prover.rs:106-111)
-    std::vector<gl_t> fin_il(2 * cur_n);
-    {
-        std::vector<gl_t> fin(2 * cur_n);
-        GL_TRY(d2h(ctx, fin.data(), coef_a.p, 2 * cur_n * sizeof(gl_t)));
-        for (size_t i = 0; i < cur_n; i++) { fin_il[2 * i] = fin[i]; fin_il[2 * i + 1] = fin[cur_n + i]; }
-    }
-    ch.observe_many(fin_il.data(), fin_il.size());
+    ctx->timing_end();
+    GL_REQUIRE(res != ~0ull, GL_ERR_INTERNAL, "Proof of work failed. This is highly unlikely!");
+    *witness = (uint64_t)res;
+    return GL_OK;
+}
 
-    // ---- fri_proof_of_work (fri/prover.rs:115-160): smallest valid witness ----
-    gl_t pow_witness = 0;
-    {
-        GL_TRY(ctx->ensure_dev_small(1 << 20));
-        unsigned long long* d_res = (unsigned long long*)ctx->dev_small;
-        GlPowParams pw;
-        for (int i = 0; i < 12; i++) pw.state[i] = ch.state[i];
-        for (int i = 0; i < ch.nin; i++) pw.state[i] = ch.in[i];
-        pw.pos = (uint32_t)ch.nin; pw.min_leading_zeros = d.proof_of_work_bits; pw.result = d_res;
-        // expected 2^pow_bits candidates: scan ascending windows of 2 * 2^pow_bits (86 % hit rate each) so that little work
-        // is wasted; the window's atomicMin keeps the result the global minimum
-        const uint64_t batch = uint64_t(2) << d.proof_of_work_bits;
-        unsigned long long res = ~0ull;
-        ctx->timing_begin("find proof-of-work witness");
-        for (uint64_t base = 0; base < GL_P; base += batch) {
-            GL_CHECK_HIP(hipMemsetAsync(d_res, 0xFF, sizeof(unsigned long long), st));
-            pw.base = base; pw.count = (GL_P - base < batch) ? GL_P - base : batch;
-            hipLaunchKernelGGL(k_pow_grind, dim3((unsigned)((pw.count + 255) / 256)), dim3(256), 0, st, pw);
-            GL_CHECK_HIP(hipGetLastError());
-            GL_TRY(d2h(ctx, &res, d_res, sizeof res));
-            if (res != ~0ull) break;
-        }
-        ctx->timing_end();
-        GL_REQUIRE(res != ~0ull, GL_ERR_INTERNAL, "Proof of work failed. This is highly unlikely!");
-        pow_witness = (gl_t)res;
-    }
-    ch.observe(pow_witness);
-    const gl_t pow_response = ch.challenge();
-    GL_REQUIRE(pow_response == 0 || (uint32_t)__builtin_clzll(pow_response) >= d.proof_of_work_bits, GL_ERR_INTERNAL, "PoW response mismatch");
-
-    // ---- query rounds (fri/prover.rs:162-216) ----
-    const uint32_t nq = d.num_query_rounds;
-    std::vector<uint32_t> x_index(nq);
-    for (uint32_t q = 0; q < nq; q++) { x_index[q] = (uint32_t)(ch.challenge() % (uint64_t)N); proof->query_indices.push_back(x_index[q]); }
+// ---- fri_prover_query_rounds (fri/prover.rs:162-216): the serialised FriQueryRound list
+//      (util/serialization/mod.rs:1477-1546: per query 4 x (leaf, u8 path length, siblings), then per reduction the
+//      `arity` extension evaluations and the path) ----
+static int fri_query_blob(gl_fri* f, const uint32_t* x_index, uint32_t nq, std::vector<uint8_t>& o) {
+    gl_ctx* ctx = f->ctx;
+    const gl_circuit_desc& d = f->desc;
+    hipStream_t st = ctx->stream;
+    const uint32_t lgN = f->lgN;
+    const size_t N = size_t(1) << lgN;
+    GL_REQUIRE(f->round == d.num_fri_rounds && !f->committed, GL_ERR_ARG, "gl_fri_query: reduction rounds not finished");
+    for (uint32_t q = 0; q < nq; q++) GL_REQUIRE(x_index[q] < N, GL_ERR_ARG, "gl_fri_query: query index out of range");
     // staging layout (u64 words): per oracle: rows [nq][ncols], paths [nq][levels][4]; per FRI round: leaves [nq][arity][2], paths
     struct Piece { size_t off, words; };
     std::vector<Piece> row_piece(4), path_piece(4), fleaf_piece(d.num_fri_rounds), fpath_piece(d.num_fri_rounds);
     size_t total = 0;
     const uint32_t init_levels = lgN - d.cap_height;
-    for (int o = 0; o < 4; o++) {
-        row_piece[o] = {total, nq * oracles[o]->ncols}; total += row_piece[o].words;
-        path_piece[o] = {total, (size_t)nq * init_levels * 4}; total += path_piece[o].words;
+    for (int o2 = 0; o2 < 4; o2++) {
+        row_piece[o2] = {total, nq * f->oracles[o2]->ncols}; total += row_piece[o2].words;
+        path_piece[o2] = {total, (size_t)nq * init_levels * 4}; total += path_piece[o2].words;
     }
     for (unsigned r = 0; r < d.num_fri_rounds; r++) {
-        const uint32_t ab = d.fri_arity_bits[r], lv = fri_lg[r] - ab - d.cap_height;
+        const uint32_t ab = d.fri_arity_bits[r], lv = f->lg[r] - ab - d.cap_height;
         fleaf_piece[r] = {total, (size_t)nq * (2u << ab)}; total += fleaf_piece[r].words;
         fpath_piece[r] = {total, (size_t)nq * lv * 4}; total += fpath_piece[r].words;
     }
@@ -460,7 +486,7 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     std::vector<uint32_t> idx_host((size_t)nq * (2 + d.num_fri_rounds));
     for (uint32_t q = 0; q < nq; q++) { idx_host[q] = x_index[q]; idx_host[nq + q] = host_bitrev32(x_index[q], lgN); }
     {
-        std::vector<uint32_t> xi(x_index);
+        std::vector<uint32_t> xi(x_index, x_index + nq);
         for (unsigned r = 0; r < d.num_fri_rounds; r++) for (uint32_t q = 0; q < nq; q++) { xi[q] >>= d.fri_arity_bits[r]; idx_host[(size_t)(2 + r) * nq + q] = xi[q]; }
     }
     GL_TRY(h2d_async(ctx, d_idx.p, idx_host.data(), idx_host.size() * sizeof(uint32_t)));
@@ -468,35 +494,201 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     const uint32_t* d_rows = d_leaf + nq;                     // natural LDE rows = bitrev(leaf)
     gl_t* stage = d_stage.as<gl_t>();
     ctx->timing_begin("FRI query gathers");
-    for (int o = 0; o < 4; o++) {
-        const gl_batch* b = oracles[o];
+    for (int o2 = 0; o2 < 4; o2++) {
+        const gl_batch* b = f->oracles[o2];
         const uint64_t* d_lo = nullptr;
         GL_TRY(ctx->get_offsets_table(b->tree.level_off.data(), b->tree.level_off.size(), &d_lo));
         unsigned cnt = nq * (unsigned)b->ncols;
-        hipLaunchKernelGGL(k_gather_rows, dim3((cnt + 255) / 256), dim3(256), 0, st, b->lde, (uint64_t)N, (uint32_t)b->ncols, d_rows, nq, stage + row_piece[o].off);
+        hipLaunchKernelGGL(k_gather_rows, dim3((cnt + 255) / 256), dim3(256), 0, st, b->lde, (uint64_t)N, (uint32_t)b->ncols, d_rows, nq, stage + row_piece[o2].off);
         cnt = nq * init_levels * 4;
-        if (cnt) hipLaunchKernelGGL(k_gather_paths, dim3((cnt + 255) / 256), dim3(256), 0, st, b->tree.digests, d_lo, init_levels, d_leaf, nq, stage + path_piece[o].off);
+        if (cnt) hipLaunchKernelGGL(k_gather_paths, dim3((cnt + 255) / 256), dim3(256), 0, st, b->tree.digests, d_lo, init_levels, d_leaf, nq, stage + path_piece[o2].off);
     }
     for (unsigned r = 0; r < d.num_fri_rounds; r++) {
-        const uint32_t ab = d.fri_arity_bits[r], lv = fri_lg[r] - ab - d.cap_height;
-        const GlMerkle& t = fri_trees[r]->m;
+        const uint32_t ab = d.fri_arity_bits[r], lv = f->lg[r] - ab - d.cap_height;
+        const GlMerkle& t = f->trees[r]->m;
         const uint64_t* d_lo = nullptr;
         GL_TRY(ctx->get_offsets_table(t.level_off.data(), t.level_off.size(), &d_lo));
-        const gl_t* va = fri_vals[r]->as<gl_t>(); const gl_t* vb = va + (size_t(1) << fri_lg[r]);
+        const gl_t* va = f->vals[r]->as<gl_t>(); const gl_t* vb = va + (size_t(1) << f->lg[r]);
         const uint32_t* d_fl = d_idx.as<uint32_t>() + (size_t)(2 + r) * nq;
         unsigned cnt = nq << ab;
-        hipLaunchKernelGGL(k_gather_fri_leaves, dim3((cnt + 255) / 256), dim3(256), 0, st, va, vb, fri_lg[r], ab, d_fl, nq, stage + fleaf_piece[r].off);
+        hipLaunchKernelGGL(k_gather_fri_leaves, dim3((cnt + 255) / 256), dim3(256), 0, st, va, vb, f->lg[r], ab, d_fl, nq, stage + fleaf_piece[r].off);
         cnt = nq * lv * 4;
         if (cnt) hipLaunchKernelGGL(k_gather_paths, dim3((cnt + 255) / 256), dim3(256), 0, st, t.digests, d_lo, lv, d_fl, nq, stage + fpath_piece[r].off);
     }
     ctx->timing_end();
     GL_CHECK_HIP(hipGetLastError());
     std::vector<gl_t> host_stage(total + 8);
-    GL_TRY(d2h(ctx, host_stage.data(), stage, total * sizeof(gl_t)));
+    GL_TRY(d2h(ctx, host_stage.data(), stage, total * sizeof(gl_t)));      // also orders the idx_host upload before it dies
+    for (uint32_t q = 0; q < nq; q++) {
+        for (int oi = 0; oi < 4; oi++) {
+            const size_t nc = f->oracles[oi]->ncols;
+            put_words(o, host_stage.data() + row_piece[oi].off + (size_t)q * nc, nc);
+            o.push_back((uint8_t)init_levels);
+            put_words(o, host_stage.data() + path_piece[oi].off + (size_t)q * init_levels * 4, (size_t)init_levels * 4);
+        }
+        for (unsigned r = 0; r < d.num_fri_rounds; r++) {
+            const uint32_t ab = d.fri_arity_bits[r], lv = f->lg[r] - ab - d.cap_height;
+            put_words(o, host_stage.data() + fleaf_piece[r].off + (size_t)q * (2u << ab), 2u << ab);
+            o.push_back((uint8_t)lv);
+            put_words(o, host_stage.data() + fpath_piece[r].off + (size_t)q * lv * 4, (size_t)lv * 4);
+        }
+    }
+    return GL_OK;
+}
+extern "C" int gl_fri_query(gl_fri* f, const uint32_t* x_index, uint32_t num_queries, uint8_t* h_blob, size_t cap_bytes, size_t* num_bytes) {
+    GL_REQUIRE(f && x_index && num_bytes, GL_ERR_ARG, "gl_fri_query: null argument");
+    GL_REQUIRE(num_queries >= 1 && num_queries <= 256, GL_ERR_ARG, "gl_fri_query: 1..256 queries");
+    GL_TRY(f->ctx->activate());
+    std::vector<uint8_t> blob;
+    GL_TRY(fri_query_blob(f, x_index, num_queries, blob));
+    *num_bytes = blob.size();
+    if (!h_blob) return GL_OK;
+    GL_REQUIRE(cap_bytes >= blob.size(), GL_ERR_ARG, "gl_fri_query: output too small");
+    memcpy(h_blob, blob.data(), blob.size());
+    return GL_OK;
+}
+
+// ======================================================================================================================
+// prove(): the driver (plonk/prover.rs:102-329) -- the phases above plus the transcript
+// ======================================================================================================================
+static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, bool wires_on_device, const uint64_t* h_pis, size_t npis, gl_proof** out);
+extern "C" int gl_prove(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, const uint64_t* h_pis, size_t npis, gl_proof** out) {
+    return prove_impl(ctx, cir, h_wires, false, h_pis, npis, out);
+}
+extern "C" int gl_prove_device(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t* h_pis, size_t npis, gl_proof** out) {
+    return prove_impl(ctx, cir, d_wires, true, h_pis, npis, out);
+}
+static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, bool wires_on_device, const uint64_t* h_pis, size_t npis, gl_proof** out) {
+    GL_REQUIRE(ctx && cir && h_wires && h_pis && out, GL_ERR_ARG, "gl_prove: null argument");
+    // circuit data is read-only while proving: any context (stream) of the same device may prove against it
+    GL_REQUIRE(cir->ctx->device == ctx->device, GL_ERR_ARG, "gl_prove: circuit lives on another device");
+    const gl_circuit_desc& d = cir->desc;
+    GL_REQUIRE(npis == d.num_public_inputs, GL_ERR_ARG, "gl_prove: wrong number of public inputs");
+    GL_TRY(ctx->activate());
+    const size_t n = cir->n, N = n << d.rate_bits;
+    const uint32_t lgn = d.degree_bits, ncap = 4u << d.cap_height;
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<gl_proof> proof(new gl_proof());
+    std::vector<gl_t> h_apow_quot;          // source of an async upload: alive until the function returns (after the last sync)
+
+    // ---- 4. wires commitment (prover.rs:145-156) ----
+    DevBuf d_wit(ctx);
+    const gl_t* d_wires = (const gl_t*)h_wires;
+    if (!wires_on_device) {
+        GL_TRY(d_wit.alloc(135 * n * sizeof(gl_t)));
+        ctx->timing_begin("H2D witness");
+        GL_CHECK_HIP(hipMemcpyAsync(d_wit.p, h_wires, 135 * n * sizeof(gl_t), hipMemcpyHostToDevice, st));
+        ctx->timing_end();
+        d_wires = d_wit.as<gl_t>();
+    }
+    BatchHolder wires; GL_TRY(gl_batch_from_device(ctx, d_wires, 135, n, d.rate_bits, d.cap_height, 1, &wires.b));
+    // public_inputs_hash (prover.rs:126-127) on the host while the GPU commits
+    gl_t pi_hash[4];
+    glhost::host_hash_no_pad(h_pis, npis, pi_hash);
+    HostChallenger ch;
+    ch.observe_many(cir->circuit_digest, 4);
+    ch.observe_many(pi_hash, 4);
+    std::vector<gl_t> cap(ncap);
+    GL_TRY(gl_batch_cap(wires.b, cap.data()));
+    proof->caps.insert(proof->caps.end(), cap.begin(), cap.end());
+    ch.observe_many(cap.data(), ncap);
+    gl_t betas[2], gammas[2], alphas[2];
+    for (int i = 0; i < 2; i++) betas[i] = ch.challenge();
+    for (int i = 0; i < 2; i++) gammas[i] = ch.challenge();
+
+    // ---- 6/7. partial products and Z, commitment (prover.rs:189-223) ----
+    BatchHolder zs;
+    {
+        DevBuf d_zs(ctx); GL_TRY(d_zs.alloc(20 * n * sizeof(gl_t)));
+        GL_TRY(partial_products_values(ctx, cir, d_wires, betas, gammas, d_zs.as<gl_t>()));
+        if (ctx->capture_intermediates) { proof->zs_pp.resize(20 * n); GL_TRY(d2h(ctx, proof->zs_pp.data(), d_zs.p, 20 * n * sizeof(gl_t))); }
+        GL_TRY(gl_batch_from_device(ctx, d_zs.as<uint64_t>(), 20, n, d.rate_bits, d.cap_height, 1, &zs.b));
+    }
+    d_wit.release();                                                            // stream-ordered: the kernels above are already queued
+    GL_TRY(gl_batch_cap(zs.b, cap.data()));
+    proof->caps.insert(proof->caps.end(), cap.begin(), cap.end());
+    ch.observe_many(cap.data(), ncap);
+    for (int i = 0; i < 2; i++) alphas[i] = ch.challenge();
+
+    // ---- 9/10. quotient polynomials (prover.rs:229-271) ----
+    BatchHolder quot;
+    {
+        DevBuf d_q(ctx); GL_TRY(d_q.alloc(2 * N * sizeof(gl_t)));
+        GL_TRY(quotient_chunks(ctx, cir, wires.b, zs.b, pi_hash, betas, gammas, alphas, d_q.as<gl_t>(), h_apow_quot));
+        if (ctx->capture_intermediates) { proof->quotient.resize(16 * n); GL_TRY(d2h(ctx, proof->quotient.data(), d_q.p, 16 * n * sizeof(gl_t))); }
+        GL_TRY(gl_batch_from_device(ctx, d_q.as<uint64_t>(), 16, n, d.rate_bits, d.cap_height, 0, &quot.b));
+    }
+    GL_TRY(gl_batch_cap(quot.b, cap.data()));
+    proof->caps.insert(proof->caps.end(), cap.begin(), cap.end());
+    ch.observe_many(cap.data(), ncap);
+
+    // ---- 11. zeta (prover.rs:273-283) ----
+    gl2_t zeta; zeta.a = ch.challenge(); zeta.b = ch.challenge();
+    {
+        gl2_t zn = zeta;
+        for (uint32_t i = 0; i < lgn; i++) zn = gl2_mul(zn, zn);
+        zn = gl2_canon(zn);
+        if (zn.a == 1 && zn.b == 0) return gl_fail(GL_ERR_ZETA_IN_SUBGROUP, "Opening point is in the subgroup.", __FILE__, __LINE__);
+    }
+    const gl2_t gzeta = gl2_canon(gl2_scalar(zeta, gl_host_root_of_unity(lgn)));
+
+    // ---- 12. openings (proof.rs:306-344): all five evaluations behind one sync ----
+    const gl_batch* oracles[4] = {cir->cs_batch, wires.b, zs.b, quot.b};
+    const size_t ncs = d.num_constants + 80, nopen = ncs + 135 + 20 + 16;
+    std::vector<gl_t> open_zeta(2 * nopen), open_next(2 * 2);
+    {
+        GL_TRY(ctx->ensure_dev_small(1 << 20));
+        gl_t* d_open = ctx->dev_small + 4096;
+        size_t off = 0;
+        ctx->timing_begin("construct the opening set");
+        for (int o = 0; o < 4; o++) { launch_open(ctx, oracles[o], 0, oracles[o]->ncols, zeta, d_open + 2 * off); off += oracles[o]->ncols; }
+        launch_open(ctx, zs.b, 0, 2, gzeta, d_open + 2 * nopen);
+        ctx->timing_end();
+        GL_CHECK_HIP(hipGetLastError());
+        std::vector<gl_t> tmp(2 * nopen + 4);
+        GL_TRY(d2h(ctx, tmp.data(), d_open, tmp.size() * sizeof(gl_t)));
+        memcpy(open_zeta.data(), tmp.data(), 2 * nopen * sizeof(gl_t));
+        memcpy(open_next.data(), tmp.data() + 2 * nopen, 4 * sizeof(gl_t));
+    }
+    // FriOpenings order = oracle order: constants, sigmas, wires, zs, partial products, quotient; then zs_next
+    ch.observe_many(open_zeta.data(), open_zeta.size());
+    ch.observe_many(open_next.data(), open_next.size());
+
+    // ---- 14. prove_openings (fri/oracle.rs:162-219), fri_proof (fri/prover.rs:20-66) ----
+    gl_t fri_alpha[2], zeta_w[2] = {zeta.a, zeta.b};
+    fri_alpha[0] = ch.challenge(); fri_alpha[1] = ch.challenge();
+    gl_fri* fri_raw = nullptr;
+    GL_TRY(gl_fri_combine(ctx, cir, oracles, zeta_w, fri_alpha, &fri_raw));
+    std::unique_ptr<gl_fri, void (*)(gl_fri*)> fri(fri_raw, gl_fri_free);
+    std::vector<gl_t> fri_caps, fri_betas;
+    for (unsigned r = 0; r < d.num_fri_rounds; r++) {
+        GL_TRY(gl_fri_commit_round(fri.get(), cap.data()));
+        fri_caps.insert(fri_caps.end(), cap.begin(), cap.end());
+        ch.observe_many(cap.data(), ncap);
+        gl_t beta[2]; beta[0] = ch.challenge(); beta[1] = ch.challenge();
+        fri_betas.push_back(beta[0]); fri_betas.push_back(beta[1]);
+        GL_TRY(gl_fri_fold(fri.get(), beta));
+    }
+    size_t fin_words = 0;
+    GL_TRY(gl_fri_final_poly(fri.get(), nullptr, 0, &fin_words));
+    std::vector<gl_t> fin_il(fin_words);
+    GL_TRY(gl_fri_final_poly(fri.get(), fin_il.data(), fin_il.size(), &fin_words));
+    ch.observe_many(fin_il.data(), fin_il.size());
+    gl_t pow_witness = 0;
+    GL_TRY(gl_pow_grind(ctx, ch.state, ch.in, (uint32_t)ch.nin, d.proof_of_work_bits, &pow_witness));
+    ch.observe(pow_witness);
+    const gl_t pow_response = ch.challenge();
+    GL_REQUIRE(pow_response == 0 || (uint32_t)__builtin_clzll(pow_response) >= d.proof_of_work_bits, GL_ERR_INTERNAL, "PoW response mismatch");
+    const uint32_t nq = d.num_query_rounds;
+    std::vector<uint32_t> x_index(nq);
+    for (uint32_t q = 0; q < nq; q++) { x_index[q] = (uint32_t)(ch.challenge() % (uint64_t)N); proof->query_indices.push_back(x_index[q]); }
+    std::vector<uint8_t> query_blob;
+    query_blob.reserve(200000);
+    GL_TRY(fri_query_blob(fri.get(), x_index.data(), nq, query_blob));
 
     // ---- 15. assemble ProofWithPublicInputs bytes (util/serialization/mod.rs:1939-1981) ----
     std::vector<uint8_t>& o = proof->bytes;
-    o.reserve(300000);
+    o.reserve(query_blob.size() + 8 * (npis + 2 * nopen + fin_words + 4 * ncap) + 4096);
     put_words(o, proof->caps.data(), proof->caps.size());                        // wires_cap, zs_pp_cap, quotient_cap
     // OpeningSet (:1409-1423): constants, sigmas, wires, zs, zs_next, [lookups: empty], partial products, quotient
     {
@@ -510,20 +702,7 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
         put_words(o, z + o_q, 2 * 16);
     }
     put_words(o, fri_caps.data(), fri_caps.size());
-    for (uint32_t q = 0; q < nq; q++) {
-        for (int oi = 0; oi < 4; oi++) {
-            const size_t nc = oracles[oi]->ncols;
-            put_words(o, host_stage.data() + row_piece[oi].off + (size_t)q * nc, nc);
-            o.push_back((uint8_t)init_levels);
-            put_words(o, host_stage.data() + path_piece[oi].off + (size_t)q * init_levels * 4, (size_t)init_levels * 4);
-        }
-        for (unsigned r = 0; r < d.num_fri_rounds; r++) {
-            const uint32_t ab = d.fri_arity_bits[r], lv = fri_lg[r] - ab - d.cap_height;
-            put_words(o, host_stage.data() + fleaf_piece[r].off + (size_t)q * (2u << ab), 2u << ab);
-            o.push_back((uint8_t)lv);
-            put_words(o, host_stage.data() + fpath_piece[r].off + (size_t)q * lv * 4, (size_t)lv * 4);
-        }
-    }
+    o.insert(o.end(), query_blob.begin(), query_blob.end());
     put_words(o, fin_il.data(), fin_il.size());
     put_u64(o, pow_witness);
     put_u64(o, npis);
@@ -533,7 +712,7 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     for (int i = 0; i < 2; i++) cv.push_back(betas[i]);
     for (int i = 0; i < 2; i++) cv.push_back(gammas[i]);
     for (int i = 0; i < 2; i++) cv.push_back(alphas[i]);
-    cv.push_back(zeta.a); cv.push_back(zeta.b); cv.push_back(fri_alpha.a); cv.push_back(fri_alpha.b); cv.push_back(pow_witness);
+    cv.push_back(zeta.a); cv.push_back(zeta.b); cv.push_back(fri_alpha[0]); cv.push_back(fri_alpha[1]); cv.push_back(pow_witness);
     for (int i = 0; i < 4; i++) cv.push_back(pi_hash[i]);
     cv.insert(cv.end(), fri_betas.begin(), fri_betas.end());
     GL_CHECK_HIP(hipStreamSynchronize(st));
@@ -557,13 +736,20 @@ extern "C" int gl_proof_caps(const gl_proof* p, uint64_t* h_out) {
     memcpy(h_out, p->caps.data(), p->caps.size() * sizeof(gl_t));
     return GL_OK;
 }
+extern "C" int gl_ctx_capture_intermediates(gl_ctx* ctx, int enable) {
+    GL_REQUIRE(ctx, GL_ERR_ARG, "null context");
+    ctx->capture_intermediates = enable != 0;
+    return GL_OK;
+}
 extern "C" int gl_proof_zs_partial_products(const gl_proof* p, uint64_t* h_out) {
     GL_REQUIRE(p && h_out, GL_ERR_ARG, "null argument");
+    GL_REQUIRE(!p->zs_pp.empty(), GL_ERR_ARG, "intermediates were not captured: call gl_ctx_capture_intermediates(ctx, 1) before proving");
     memcpy(h_out, p->zs_pp.data(), p->zs_pp.size() * sizeof(gl_t));
     return GL_OK;
 }
 extern "C" int gl_proof_quotient_chunks(const gl_proof* p, uint64_t* h_out) {
     GL_REQUIRE(p && h_out, GL_ERR_ARG, "null argument");
+    GL_REQUIRE(!p->quotient.empty(), GL_ERR_ARG, "intermediates were not captured: call gl_ctx_capture_intermediates(ctx, 1) before proving");
     memcpy(h_out, p->quotient.data(), p->quotient.size() * sizeof(gl_t));
     return GL_OK;
 }

@@ -31,4 +31,5 @@ def gpu():
     """The product library with a live context; fails loudly if the HIP extension or the GPU is missing."""
     import plonky2_demo_amd as p
     ctx = p.default_context()
+    ctx.capture_intermediates(True)       # the parity tests compare Z / partial products and quotient chunks too
     return p, ctx

@@ -314,3 +314,102 @@ def test_prove_m128_config5(gpu, orc):
     ok, msg = v.verify_bytes(by, cd.constants_sigmas_cap, cd.circuit_digest)
     assert ok, msg
     assert len(pr.challenges()["fri_betas"]) == 4
+
+
+# ------------------------------------------------------------------------------- phase-level ABI (SURVEY 8b seam)
+class _Challenger:
+    """iop/challenger.rs:30-153 as the reference-side caller would keep it (here in Python, permutation from the oracle)."""
+
+    def __init__(self, orc):
+        self.orc, self.state, self.inp, self.out = orc, [0] * 12, [], []
+
+    def _duplex(self):
+        for i, x in enumerate(self.inp):
+            self.state[i] = x
+        self.inp = []
+        self.state = [int(x) for x in self.orc.poseidon(np.array(self.state, dtype=np.uint64))]
+        self.out = self.state[:8]
+
+    def observe(self, xs):
+        for x in np.asarray(xs, dtype=np.uint64).reshape(-1):
+            self.out = []
+            self.inp.append(int(x))
+            if len(self.inp) == 8:
+                self._duplex()
+
+    def get(self, k):
+        r = []
+        for _ in range(k):
+            if self.inp or not self.out:
+                self._duplex()
+            r.append(self.out.pop() % P)
+        return r
+
+
+@pytest.mark.parametrize("m", [2, 8, 20])
+def test_phase_api_with_external_transcript_reproduces_the_proof(gpu, orc, m):
+    # every phase entry point of include/plonky2_mi355x.h driven by a caller-side Challenger, in the order of
+    # plonk/prover.rs:102-329; the assembled ProofWithPublicInputs bytes equal the oracle's (and gl_prove's)
+    p, ctx = gpu
+    hc = p.MatmulCircuit(m)
+    n, N, d = hc.n, hc.n << 3, hc.desc
+    a, b = rand_field(7000 + m, m * m) % (2**32 - 1), rand_field(7001 + m, m * m) % (2**32 - 1)
+    wires, pis = hc.witness(a, b, filler_seed=m)
+    cd = hc.build()
+    op = orc.circuit(m, threads=8).witness(a, b, filler_seed=m).prove(threads=8)
+
+    d_w = ctx.alloc(wires.nbytes).upload(wires)
+    ch = _Challenger(orc)
+    pi_hash = orc.hash_no_pad(pis)
+    ch.observe(cd.circuit_digest); ch.observe(pi_hash)
+    wires_b = p.PolynomialBatch.from_device(d_w.ptr, 135, n, d.rate_bits, d.cap_height, True)
+    ch.observe(wires_b.cap)
+    betas, gammas = ch.get(2), ch.get(2)
+    zs_b = cd.partial_products(d_w.ptr, betas, gammas)
+    assert (d_w.download(wires.shape) == wires).all()                  # the witness matrix is left untouched
+    ch.observe(zs_b.cap)
+    alphas = ch.get(2)
+    q_b = cd.quotient_polys(wires_b, zs_b, pi_hash, betas, gammas, alphas)
+    assert (q_b.polynomials == op.quotient_chunks()).all()
+    ch.observe(q_b.cap)
+    zeta = ch.get(2)
+    g = orc.primitive_root(hc.degree_bits)
+    gzeta = [zeta[0] * g % P, zeta[1] * g % P]
+    cs_b = cd.constants_sigmas_batch
+    o_cs, o_w, o_z, o_q = cs_b.open_at(zeta), wires_b.open_at(zeta), zs_b.open_at(zeta), q_b.open_at(zeta)
+    o_next = zs_b.open_at(gzeta, 0, 2)
+    assert (zs_b.open_at(zeta, 2, 18) == o_z[2:]).all()
+    for o in (o_cs, o_w, o_z, o_q, o_next):
+        ch.observe(o)
+    fri_alpha = ch.get(2)
+    fri = cd.fri([cs_b, wires_b, zs_b, q_b], zeta, fri_alpha)
+    fri_caps = []
+    with pytest.raises(p.Plonky2Mi355xError):
+        fri.fold([1, 0])                                                    # fold before commit
+    for _ in range(d.num_fri_rounds):
+        cap = fri.commit_round()
+        fri_caps.append(cap)
+        ch.observe(cap)
+        fri.fold(ch.get(2))
+    with pytest.raises(p.Plonky2Mi355xError):
+        fri.commit_round()                                                  # no round left
+    fin = fri.final_poly()
+    ch.observe(fin)
+    w = p.pow_grind(ch.state, ch.inp, d.proof_of_work_bits)
+    ch.observe([w])
+    resp = ch.get(1)[0]
+    assert resp >> (64 - d.proof_of_work_bits) == 0
+    x_index = [ch.get(1)[0] % N for _ in range(d.num_query_rounds)]
+    blob = fri.query(x_index)
+
+    le = lambda arr: np.ascontiguousarray(np.asarray(arr, dtype="<u8")).tobytes()
+    by = le(wires_b.cap) + le(zs_b.cap) + le(q_b.cap)
+    by += le(o_cs) + le(o_w) + le(o_z[:2]) + le(o_next) + le(o_z[2:]) + le(o_q)       # util/serialization/mod.rs:1409-1423
+    by += b"".join(le(c) for c in fri_caps) + blob + le(fin) + le([w]) + le([pis.size]) + le(pis)
+    ob = op.to_bytes()
+    assert len(by) == len(ob)
+    assert by == ob
+    assert by == cd.prove(wires, pis).to_bytes()
+    assert op.challenges()["pow_witness"] == w and op.query_indices() == x_index
+    for h in (fri, q_b, zs_b, wires_b):
+        del h
