@@ -180,6 +180,14 @@ int gl_host_circuit_constants_sigmas(const gl_host_circuit* hc, uint64_t* h_out)
 int gl_matmul_witness(const gl_host_circuit* hc, const uint64_t* h_a, const uint64_t* h_b, uint64_t filler_seed,
                       uint64_t* h_wires, uint64_t* h_public_inputs);
 void gl_host_circuit_free(gl_host_circuit* hc);
+/* The same witness produced directly in HBM: the m^3 ArithmeticGate operations are filled by the GPU, the sequential
+ * public-input hash sponge (PoseidonGate rows) by the calling host thread meanwhile.  d_wires[135][n] is overwritten;
+ * h_public_inputs[3 m^2].  The generator borrows `hc` and belongs to `ctx` (one per context / stream). */
+typedef struct gl_matmul_witgen gl_matmul_witgen;
+int gl_matmul_witgen_create(gl_ctx* ctx, const gl_host_circuit* hc, gl_matmul_witgen** out);
+int gl_matmul_witgen_run(gl_matmul_witgen* g, const uint64_t* a, const uint64_t* b, uint64_t filler_seed,
+                         uint64_t* d_wires, uint64_t* h_public_inputs);
+void gl_matmul_witgen_free(gl_matmul_witgen* g);
 
 /* The device half of build(): PolynomialBatch::from_values(constants || sigmas) (circuit_builder.rs:1020-1028),
  * circuit_digest (:1089-1100), sigma / subgroup tables.  h_constants_sigmas[(num_constants + 80)][n]. */

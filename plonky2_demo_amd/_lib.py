@@ -85,6 +85,9 @@ SIGNATURES = {
     "gl_host_circuit_constants_sigmas": (c_int, [c_vp, c_vp]),
     "gl_matmul_witness": (c_int, [c_vp, c_vp, c_vp, c_u64, c_vp, c_vp]),
     "gl_host_circuit_free": (None, [c_vp]),
+    "gl_matmul_witgen_create": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
+    "gl_matmul_witgen_run": (c_int, [c_vp, c_vp, c_vp, c_u64, c_vp, c_vp]),
+    "gl_matmul_witgen_free": (None, [c_vp]),
     "gl_circuit_create": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "gl_circuit_from_host": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "gl_circuit_digest": (c_int, [c_vp, c_vp]),

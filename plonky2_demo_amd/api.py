@@ -403,6 +403,10 @@ class MatmulCircuit:
         check(lib.gl_matmul_witness(self.handle, _p(a), _p(b), filler_seed, _p(wires), _p(pis)))
         return wires, pis
 
+    def witness_generator(self, ctx=None):
+        """Witness generation straight into HBM (GPU arithmetic rows + host hash-sponge rows), one per context."""
+        return WitnessGenerator(self, _ctx(ctx))
+
     def build(self, ctx=None):
         """CircuitBuilder::build(): the device half (constants/sigmas commitment, digest)."""
         return CircuitData(self, _ctx(ctx))
@@ -411,6 +415,33 @@ class MatmulCircuit:
         try:
             if self.handle:
                 lib.gl_host_circuit_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class WitnessGenerator:
+    """generate_partial_witness + full_witness (plonk/prover.rs:118-133) for the matmul family, wire matrix in HBM."""
+
+    def __init__(self, host, ctx):
+        self.host, self.ctx = host, ctx
+        h = ctypes.c_void_p()
+        check(lib.gl_matmul_witgen_create(ctx.handle, host.handle, ctypes.byref(h)))
+        self.handle = h.value
+
+    def run(self, a, b, d_wires_ptr, filler_seed=0x504C4F4E4B5932):
+        """Overwrites the device matrix d_wires[135][n]; returns the public inputs."""
+        a, b = _u64(a).reshape(-1), _u64(b).reshape(-1)
+        if a.size != self.host.m ** 2 or b.size != self.host.m ** 2:
+            raise ValueError("a and b must be m x m")
+        pis = np.empty(3 * self.host.m ** 2, dtype=np.uint64)
+        check(lib.gl_matmul_witgen_run(self.handle, _p(a), _p(b), filler_seed, d_wires_ptr, _p(pis)))
+        return pis
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.gl_matmul_witgen_free(self.handle)
                 self.handle = None
         except Exception:
             pass

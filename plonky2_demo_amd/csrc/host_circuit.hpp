@@ -286,3 +286,5 @@ inline int matmul_witness(const HostCircuit& hc, const gl_t* a, const gl_t* b, u
 }
 
 }  // namespace glhost
+
+struct gl_host_circuit { glhost::HostCircuit hc; };     // the opaque handle of include/plonky2_mi355x.h

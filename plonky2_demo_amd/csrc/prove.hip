@@ -10,8 +10,6 @@
 
 using glhost::HostCircuit;
 
-struct gl_host_circuit { HostCircuit hc; };
-
 struct gl_circuit {
     gl_ctx* ctx = nullptr;
     gl_circuit_desc desc;

@@ -1,0 +1,147 @@
+// Witness generation for the matmul circuit family with the wire matrix produced directly in HBM
+// (the reference's generate_partial_witness + full_witness, plonky2/src/plonk/prover.rs:118-133, iop/generator.rs:19-98,
+// specialised to the generators this circuit installs: ArithmeticBaseGenerator gates/arithmetic_base.rs:184-225,
+// PoseidonGenerator gates/poseidon.rs:430-497, the PublicInputGate / ConstantGate copies, RandomValueGenerator
+// iop/generator.rs and circuit_builder.rs:904-910).
+//
+// Split by what each side is good at:
+//   * the m^3 ArithmeticGate operations are independent per output C[i][j]: one GPU lane per output walks its k-chain and
+//     scatters the 4 wires of every multiply / add operation into the column-major matrix;
+//   * the public-input hash is ONE sequential sponge of 3m^2/8 permutations whose every intermediate S-box input is a
+//     wire: inherently serial, done on the host core that drives the context while the GPU fills the arithmetic rows,
+//     then uploaded as one strided copy (the PoseidonGate rows, the PublicInputGate row and the ConstantGate row are
+//     consecutive rows of the trace).
+// The result is bit-identical to gl_matmul_witness (host) -- tests/test_gpu_parity.py.
+#include "context.hpp"
+#include "host_circuit.hpp"
+#include <memory>
+
+struct gl_matmul_witgen {
+    gl_ctx* ctx = nullptr;
+    const gl_host_circuit* hc = nullptr;                 // borrowed: must outlive the generator
+    uint32_t* d_mul_row = nullptr; uint32_t* d_add_row = nullptr;
+    gl_t* d_ab = nullptr;                                // a then b, m*m each
+    gl_t* h_special = nullptr;                           // pinned [135][R] staging of the non-arithmetic rows
+    gl_t* h_ab = nullptr;                                // pinned copy of the operands
+    size_t R = 0;
+    std::vector<gl_t> cvals;
+};
+
+// one lane per output (i, j): the reference's loop order `for i, for j, for k` (matrix_mul.rs:46-58) fixes the operation
+// indices: multiply t = (i*m + j)*m + k, add t' = (i*m + j)*(m-1) + (k-1); operation t sits in slot t % 20 of row-block
+// t / 20 of its kind (gadgets/arithmetic.rs:87-99)
+__global__ void k_matmul_arith_rows(const gl_t* __restrict__ a, const gl_t* __restrict__ b, uint32_t m, uint64_t n,
+                                    const uint32_t* __restrict__ mul_row, const uint32_t* __restrict__ add_row, gl_t* __restrict__ wires) {
+    const uint32_t ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= m * m) return;
+    const uint32_t i = ij / m, j = ij - i * m;
+    uint64_t mc = (uint64_t)ij * m, ac = (uint64_t)ij * (m - 1);
+    gl_t cur = 0;
+    for (uint32_t k = 0; k < m; k++, mc++) {
+        const gl_t x = gl_canon(a[i * m + k]), y = gl_canon(b[k * m + j]), p = gl_canon(gl_mul(x, y));
+        {   // mul(x, y) = arithmetic(1, 0, x, y, x): wires multiplicand_0, multiplicand_1, addend, output
+            const uint64_t row = mul_row[mc / 20]; const uint32_t s = (uint32_t)(mc % 20);
+            gl_t* w = wires + (uint64_t)(4 * s) * n + row;
+            w[0] = x; w[n] = y; w[2 * n] = x; w[3 * n] = p;
+        }
+        if (k == 0) { cur = p; continue; }
+        const gl_t sum = gl_canon(gl_add(cur, p));
+        {   // add(cur, p) = arithmetic(1, 1, cur, one, p)
+            const uint64_t row = add_row[ac / 20]; const uint32_t s = (uint32_t)(ac % 20);
+            gl_t* w = wires + (uint64_t)(4 * s) * n + row;
+            w[0] = cur; w[n] = 1; w[2 * n] = p; w[3 * n] = sum;
+        }
+        ac++;
+        cur = sum;
+    }
+}
+
+extern "C" void gl_matmul_witgen_free(gl_matmul_witgen* g) {
+    if (!g) return;
+    if (g->ctx) {
+        (void)g->ctx->activate();
+        (void)hipStreamSynchronize(g->ctx->stream);
+        if (g->d_mul_row) g->ctx->pool_release(g->d_mul_row);
+        if (g->d_add_row) g->ctx->pool_release(g->d_add_row);
+        if (g->d_ab) g->ctx->pool_release(g->d_ab);
+    }
+    if (g->h_special) (void)hipHostFree(g->h_special);
+    if (g->h_ab) (void)hipHostFree(g->h_ab);
+    delete g;
+}
+
+extern "C" int gl_matmul_witgen_create(gl_ctx* ctx, const gl_host_circuit* hc, gl_matmul_witgen** out) {
+    GL_REQUIRE(ctx && hc && out, GL_ERR_ARG, "gl_matmul_witgen_create: null argument");
+    GL_TRY(ctx->activate());
+    const glhost::HostCircuit& h = hc->hc;
+    GL_REQUIRE(h.constant_row == h.first_poseidon_row + h.num_poseidon_rows + 1 && h.pi_row + 1 == h.constant_row, GL_ERR_INTERNAL,
+               "matmul trace layout: PoseidonGate rows, PublicInputGate row and ConstantGate row must be consecutive");
+    std::unique_ptr<gl_matmul_witgen, void (*)(gl_matmul_witgen*)> g(new gl_matmul_witgen(), gl_matmul_witgen_free);
+    g->ctx = ctx; g->hc = hc; g->R = h.num_poseidon_rows + 2;
+    const size_t mm = h.m * h.m;
+    GL_TRY(ctx->pool_alloc((h.mul_row.size() + 1) * sizeof(uint32_t), (void**)&g->d_mul_row));
+    GL_TRY(ctx->pool_alloc((h.add_row.size() + 1) * sizeof(uint32_t), (void**)&g->d_add_row));
+    GL_TRY(ctx->pool_alloc(2 * mm * sizeof(gl_t), (void**)&g->d_ab));
+    GL_CHECK_HIP(hipHostMalloc((void**)&g->h_special, 135 * g->R * sizeof(gl_t), hipHostMallocDefault));
+    GL_CHECK_HIP(hipHostMalloc((void**)&g->h_ab, 2 * mm * sizeof(gl_t), hipHostMallocDefault));
+    GL_TRY(gl_copy_h2d(ctx, g->d_mul_row, h.mul_row.data(), h.mul_row.size() * sizeof(uint32_t)));
+    if (!h.add_row.empty()) GL_TRY(gl_copy_h2d(ctx, g->d_add_row, h.add_row.data(), h.add_row.size() * sizeof(uint32_t)));
+    g->cvals.resize(mm);
+    *out = g.release();
+    return GL_OK;
+}
+
+extern "C" int gl_matmul_witgen_run(gl_matmul_witgen* g, const uint64_t* a, const uint64_t* b, uint64_t filler_seed, uint64_t* d_wires, uint64_t* h_pis) {
+    GL_REQUIRE(g && a && b && d_wires && h_pis, GL_ERR_ARG, "gl_matmul_witgen_run: null argument");
+    gl_ctx* ctx = g->ctx;
+    GL_TRY(ctx->activate());
+    const glhost::HostCircuit& h = g->hc->hc;
+    const size_t m = h.m, n = h.n, mm = m * m, R = g->R;
+    hipStream_t st = ctx->stream;
+    using namespace glhost;
+
+    // --- GPU: zero the trace, then the arithmetic rows ---
+    for (size_t t = 0; t < mm; t++) { g->h_ab[t] = gl_canon(a[t]); g->h_ab[mm + t] = gl_canon(b[t]); }
+    ctx->timing_begin("witness: arithmetic rows");
+    GL_CHECK_HIP(hipMemsetAsync(d_wires, 0, 135 * n * sizeof(gl_t), st));
+    GL_CHECK_HIP(hipMemcpyAsync(g->d_ab, g->h_ab, 2 * mm * sizeof(gl_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_matmul_arith_rows, dim3((unsigned)((mm + 63) / 64)), dim3(64), 0, st, g->d_ab, g->d_ab + mm, (uint32_t)m, (uint64_t)n,
+                       g->d_mul_row, g->d_add_row, (gl_t*)d_wires);
+    ctx->timing_end();
+    GL_CHECK_HIP(hipGetLastError());
+
+    // --- host, meanwhile: C, the public inputs, the PI-hash sponge rows, the PublicInputGate and ConstantGate rows ---
+    const gl_t* ha = g->h_ab; const gl_t* hb = g->h_ab + mm;
+    for (size_t i = 0; i < m; i++)
+        for (size_t j = 0; j < m; j++) {
+            gl_t cur = 0;
+            for (size_t k = 0; k < m; k++) {
+                const gl_t p = gl_canon(gl_mul(ha[i * m + k], hb[k * m + j]));
+                cur = k ? gl_canon(gl_add(cur, p)) : p;
+            }
+            g->cvals[i * m + j] = cur;
+        }
+    const size_t n_pi = 3 * mm;
+    for (size_t ij = 0; ij < mm; ij++) { h_pis[3 * ij] = ha[ij]; h_pis[3 * ij + 1] = hb[ij]; h_pis[3 * ij + 2] = g->cvals[ij]; }
+    gl_t* sp = g->h_special;                               // sp[col * R + r], r = row - first_poseidon_row
+    memset(sp, 0, 135 * R * sizeof(gl_t));
+    gl_t state[12] = {0};
+    for (size_t pr = 0; pr < h.num_poseidon_rows; pr++) {
+        const size_t off = pr * 8, c = std::min<size_t>(8, n_pi - off);
+        for (size_t t = 0; t < c; t++) state[t] = h_pis[off + t];
+        poseidon_row_witness(state, sp + pr, R);
+        for (int t = 0; t < 12; t++) state[t] = sp[(PW_OUTPUT + t) * R + pr];
+    }
+    const size_t r_pi = h.num_poseidon_rows, r_const = r_pi + 1;
+    for (int t = 0; t < 4; t++) sp[t * R + r_pi] = state[t];
+    { uint64_t s = filler_seed; for (size_t c = 4; c < 135; c++) sp[c * R + r_pi] = splitmix64_next(s) % GL_P; }   // circuit_builder.rs:904-910
+    sp[0 * R + r_const] = 0; sp[1 * R + r_const] = 1;
+
+    // --- one strided upload of the R consecutive special rows (after the memset on the same stream) ---
+    ctx->timing_begin("witness: upload hash rows");
+    GL_CHECK_HIP(hipMemcpy2DAsync((gl_t*)d_wires + h.first_poseidon_row, n * sizeof(gl_t), sp, R * sizeof(gl_t), R * sizeof(gl_t), 135,
+                                  hipMemcpyHostToDevice, st));
+    ctx->timing_end();
+    GL_CHECK_HIP(hipStreamSynchronize(st));                // the pinned staging buffers are reused by the next call
+    return GL_OK;
+}

@@ -413,3 +413,25 @@ def test_phase_api_with_external_transcript_reproduces_the_proof(gpu, orc, m):
     assert op.challenges()["pow_witness"] == w and op.query_indices() == x_index
     for h in (fri, q_b, zs_b, wires_b):
         del h
+
+
+# ------------------------------------------------------------------------------- witness generation in HBM
+@pytest.mark.parametrize("m", [1, 2, 3, 5, 20, 64])
+def test_device_witness_generation_equals_host(gpu, orc, m):
+    p, ctx = gpu
+    hc = p.MatmulCircuit(m)
+    gen = hc.witness_generator()
+    buf = ctx.alloc(135 * hc.n * 8)
+    for seed in (m, m + 100):
+        a, b = rand_field(9000 + seed, m * m), rand_field(9500 + seed, m * m)       # full-range field elements, incl. > 2^32
+        if seed == m:
+            a[0], b[-1] = P - 1, P + 5 if m > 1 else 3                               # non-canonical input is canonicalised
+        wires, pis = hc.witness(a, b, filler_seed=seed)
+        buf.upload(np.full((135, hc.n), 0xDEADBEEF, dtype=np.uint64))               # stale contents must be overwritten
+        dpis = gen.run(a, b, buf.ptr, filler_seed=seed)
+        assert (dpis == pis).all()
+        assert (buf.download((135, hc.n)) == wires).all()
+    # ... and it proves: same bytes as proving the host witness
+    if m in (2, 20):
+        cd = hc.build()
+        assert cd.prove_device(buf.ptr, dpis).to_bytes() == cd.prove(wires, pis).to_bytes()
