@@ -235,7 +235,7 @@ def _prove_both(p, orc, m, seed, threads=8):
     return gp, op
 
 
-@pytest.mark.parametrize("m", [2, 3, 8, 20])
+@pytest.mark.parametrize("m", [1, 2, 3, 5, 8, 20])
 def test_prove_is_byte_identical_to_the_oracle(gpu, orc, m):
     # BASELINE configs[0] (m = 2, README instance shape) and sizes with 0, 1 and 2 FRI reduction rounds
     p, ctx = gpu
