@@ -221,7 +221,7 @@ def main():
                     a, b = ops[i % len(ops)]
                     ptr = ctypes.c_void_p(bufs[lane].data_ptr())
                     pis = gens[lane].run(a, b, ptr, filler_seed=i)
-                    el[lane][1].prove_device(ptr, pis)
+                    el[lane][1].prove_device(ptr, pis, gens[lane].public_inputs_hash)
                 el[lane][0].synchronize()
 
             for count in (nl, args.e2e_steps):                # warm-up round, then the timed one

@@ -39,6 +39,7 @@ extern "C" {
 #define GL_ERR_UNSUPPORTED 3  /* e.g. blinding != 0 (zero-knowledge salts)            */
 #define GL_ERR_ZETA_IN_SUBGROUP 4 /* prover.rs:280-283: opening point lies in H       */
 #define GL_ERR_INTERNAL 5
+#define GL_ERR_VERIFY 6       /* gl_verify: the proof is rejected (gl_last_error says which check failed) */
 
 typedef struct gl_ctx gl_ctx;
 typedef struct gl_batch gl_batch;      /* device-resident PolynomialBatch (fri/oracle.rs:30-37)  */
@@ -186,7 +187,7 @@ void gl_host_circuit_free(gl_host_circuit* hc);
 typedef struct gl_matmul_witgen gl_matmul_witgen;
 int gl_matmul_witgen_create(gl_ctx* ctx, const gl_host_circuit* hc, gl_matmul_witgen** out);
 int gl_matmul_witgen_run(gl_matmul_witgen* g, const uint64_t* a, const uint64_t* b, uint64_t filler_seed,
-                         uint64_t* d_wires, uint64_t* h_public_inputs);
+                         uint64_t* d_wires, uint64_t* h_public_inputs, uint64_t* h_public_inputs_hash /* [4], may be null */);
 void gl_matmul_witgen_free(gl_matmul_witgen* g);
 
 /* The device half of build(): PolynomialBatch::from_values(constants || sigmas) (circuit_builder.rs:1020-1028),
@@ -250,6 +251,10 @@ int gl_prove(gl_ctx* ctx, const gl_circuit* c, const uint64_t* h_wires, const ui
 /* same with the witness matrix already resident in HBM (d_wires[num_wires][n]) */
 int gl_prove_device(gl_ctx* ctx, const gl_circuit* c, const uint64_t* d_wires, const uint64_t* h_public_inputs,
                     size_t num_public_inputs, gl_proof** out);
+/* same, with public_inputs_hash = hash_no_pad(public_inputs) (prover.rs:126-127) supplied by the caller -- the witness
+ * generator's sponge produces it as a by-product, and hashing 3 m^2 inputs is a sequential host job */
+int gl_prove_device_hashed(gl_ctx* ctx, const gl_circuit* c, const uint64_t* d_wires, const uint64_t* h_public_inputs,
+                           size_t num_public_inputs, const uint64_t public_inputs_hash[4], gl_proof** out);
 /* ProofWithPublicInputs::to_bytes (plonk/proof.rs:104-110; util/serialization/mod.rs:1939-1981) */
 size_t gl_proof_num_bytes(const gl_proof* p);
 int gl_proof_bytes(const gl_proof* p, uint8_t* h_out, size_t cap);
@@ -263,6 +268,19 @@ int gl_proof_zs_partial_products(const gl_proof* p, uint64_t* h_out /* [20][n] v
 int gl_proof_quotient_chunks(const gl_proof* p, uint64_t* h_out /* [16][n] coefficients */);
 size_t gl_proof_query_indices(const gl_proof* p, uint64_t* h_out);
 void gl_proof_free(gl_proof* p);
+
+/* ---- verify() --------------------------------------------------------------------------------------*/
+/* VerifierCircuitData::verify (plonky2/src/plonk/circuit_data.rs:208-215 -> plonk/verifier.rs:15-115, fri/verifier.rs:
+ * 62-260) for circuits over the demo's gate set: CommonCircuitData = *desc, VerifierOnlyCircuitData =
+ * (constants_sigmas_cap[2^cap_height][4], circuit_digest), proof = ProofWithPublicInputs::to_bytes().  Host code, no
+ * GPU needed (as in the reference).  GL_OK = accepted; GL_ERR_VERIFY = rejected, gl_last_error() names the failing
+ * check ("vanishing polynomial identity fails at zeta", "invalid proof of work witness", "initial Merkle proof fails",
+ * "FRI consistency check fails", "FRI step Merkle proof fails", "final polynomial evaluation is invalid",
+ * "malformed proof: ..."). */
+int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_sigmas_cap, const uint64_t circuit_digest[4],
+              const uint8_t* proof_bytes, size_t num_bytes);
+int gl_host_circuit_verify(const gl_host_circuit* hc, const uint64_t* constants_sigmas_cap, const uint64_t circuit_digest[4],
+                           const uint8_t* proof_bytes, size_t num_bytes);
 
 #ifdef __cplusplus
 }

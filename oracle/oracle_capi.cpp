@@ -316,6 +316,7 @@ void orc_proof_tamper(void* p, int what) {
         case 4: op->proof.opening_proof.query_round_proofs[5].initial[1].first[7] = add(op->proof.opening_proof.query_round_proofs[5].initial[1].first[7], 1); break;
         case 5: op->proof.quotient_cap[2].e[1] = add(op->proof.quotient_cap[2].e[1], 1); break;
     }
+    op->bytes = proof_to_bytes(op->proof);      // the serialised form follows the tampered struct
 }
 
 }  // extern "C"

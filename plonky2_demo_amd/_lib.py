@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libplonky2_mi355x.so")
 
 GL_OK = 0
-ERRORS = {1: "GL_ERR_ARG", 2: "GL_ERR_HIP", 3: "GL_ERR_UNSUPPORTED", 4: "GL_ERR_ZETA_IN_SUBGROUP", 5: "GL_ERR_INTERNAL"}
+GL_ERR_VERIFY = 6
+ERRORS = {1: "GL_ERR_ARG", 2: "GL_ERR_HIP", 3: "GL_ERR_UNSUPPORTED", 4: "GL_ERR_ZETA_IN_SUBGROUP", 5: "GL_ERR_INTERNAL", 6: "GL_ERR_VERIFY"}
 
 
 class Plonky2Mi355xError(RuntimeError):
@@ -86,7 +87,7 @@ SIGNATURES = {
     "gl_matmul_witness": (c_int, [c_vp, c_vp, c_vp, c_u64, c_vp, c_vp]),
     "gl_host_circuit_free": (None, [c_vp]),
     "gl_matmul_witgen_create": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
-    "gl_matmul_witgen_run": (c_int, [c_vp, c_vp, c_vp, c_u64, c_vp, c_vp]),
+    "gl_matmul_witgen_run": (c_int, [c_vp, c_vp, c_vp, c_u64, c_vp, c_vp, c_vp]),
     "gl_matmul_witgen_free": (None, [c_vp]),
     "gl_circuit_create": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "gl_circuit_from_host": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
@@ -107,6 +108,7 @@ SIGNATURES = {
     "gl_ctx_capture_intermediates": (c_int, [c_vp, c_int]),
     "gl_prove": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "gl_prove_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "gl_prove_device_hashed": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, ctypes.POINTER(c_vp)]),
     "gl_proof_num_bytes": (c_sz, [c_vp]),
     "gl_proof_bytes": (c_int, [c_vp, c_vp, c_sz]),
     "gl_proof_challenges": (c_sz, [c_vp, c_vp]),
@@ -115,6 +117,8 @@ SIGNATURES = {
     "gl_proof_quotient_chunks": (c_int, [c_vp, c_vp]),
     "gl_proof_query_indices": (c_sz, [c_vp, c_vp]),
     "gl_proof_free": (None, [c_vp]),
+    "gl_verify": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz]),
+    "gl_host_circuit_verify": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz]),
 }
 
 

@@ -403,6 +403,19 @@ class MatmulCircuit:
         check(lib.gl_matmul_witness(self.handle, _p(a), _p(b), filler_seed, _p(wires), _p(pis)))
         return wires, pis
 
+    def verify(self, proof_bytes, constants_sigmas_cap, circuit_digest):
+        """VerifierCircuitData::verify (plonk/circuit_data.rs:208-215): (accepted, reason).  Host code, no GPU needed."""
+        buf = np.frombuffer(bytes(proof_bytes), dtype=np.uint8)
+        cap, dig = _u64(constants_sigmas_cap), _u64(circuit_digest)
+        if cap.size != 4 << self.desc.cap_height or dig.size != 4:
+            raise ValueError("cap must be [2^cap_height][4], digest [4]")
+        st = lib.gl_host_circuit_verify(self.handle, _p(cap), _p(dig), _p(buf), buf.size)
+        if st == _lib.GL_OK:
+            return True, ""
+        if st == _lib.GL_ERR_VERIFY:
+            return False, (lib.gl_last_error() or b"").decode()
+        check(st)
+
     def witness_generator(self, ctx=None):
         """Witness generation straight into HBM (GPU arithmetic rows + host hash-sponge rows), one per context."""
         return WitnessGenerator(self, _ctx(ctx))
@@ -435,7 +448,8 @@ class WitnessGenerator:
         if a.size != self.host.m ** 2 or b.size != self.host.m ** 2:
             raise ValueError("a and b must be m x m")
         pis = np.empty(3 * self.host.m ** 2, dtype=np.uint64)
-        check(lib.gl_matmul_witgen_run(self.handle, _p(a), _p(b), filler_seed, d_wires_ptr, _p(pis)))
+        self.public_inputs_hash = np.empty(4, dtype=np.uint64)      # by-product of the sponge rows
+        check(lib.gl_matmul_witgen_run(self.handle, _p(a), _p(b), filler_seed, d_wires_ptr, _p(pis), _p(self.public_inputs_hash)))
         return pis
 
     def __del__(self):
@@ -445,6 +459,16 @@ class WitnessGenerator:
                 self.handle = None
         except Exception:
             pass
+
+
+def _prove_device(ctx, circuit_handle, n, d_wires_ptr, public_inputs, public_inputs_hash):
+    pis = _u64(public_inputs)
+    h = ctypes.c_void_p()
+    if public_inputs_hash is None:
+        check(lib.gl_prove_device(ctx.handle, circuit_handle, d_wires_ptr, _p(pis), pis.size, ctypes.byref(h)))
+    else:
+        check(lib.gl_prove_device_hashed(ctx.handle, circuit_handle, d_wires_ptr, _p(pis), pis.size, _p(_u64(public_inputs_hash)), ctypes.byref(h)))
+    return Proof(h.value, n)
 
 
 class CircuitData:
@@ -499,6 +523,11 @@ class CircuitData:
         """PolynomialBatch::prove_openings up to fri_proof (fri/oracle.rs:162-204)."""
         return FriProver(self, batches, zeta, alpha, ctx or self.ctx)
 
+    def verify(self, proof):
+        """CircuitData::verify (plonk/circuit_data.rs:153-155); `proof` is a Proof or its bytes."""
+        by = proof.to_bytes() if hasattr(proof, "to_bytes") else proof
+        return self.host.verify(by, self.constants_sigmas_cap, self.circuit_digest)
+
     def prove(self, wires, public_inputs):
         wires, pis = _u64(wires), _u64(public_inputs)
         if wires.shape != (135, self.host.n):
@@ -507,12 +536,9 @@ class CircuitData:
         check(lib.gl_prove(self.ctx.handle, self.handle, _p(wires), _p(pis), pis.size, ctypes.byref(h)))
         return Proof(h.value, self.host.n)
 
-    def prove_device(self, d_wires_ptr, public_inputs):
+    def prove_device(self, d_wires_ptr, public_inputs, public_inputs_hash=None):
         """prove() with the witness matrix already in HBM (raw device pointer to [135][n] u64)."""
-        pis = _u64(public_inputs)
-        h = ctypes.c_void_p()
-        check(lib.gl_prove_device(self.ctx.handle, self.handle, d_wires_ptr, _p(pis), pis.size, ctypes.byref(h)))
-        return Proof(h.value, self.host.n)
+        return _prove_device(self.ctx, self.handle, self.host.n, d_wires_ptr, public_inputs, public_inputs_hash)
 
     def __del__(self):
         try:
@@ -529,11 +555,8 @@ class CircuitView:
     def __init__(self, circuit_data, ctx):
         self.cd, self.ctx = circuit_data, ctx
 
-    def prove_device(self, d_wires_ptr, public_inputs):
-        pis = _u64(public_inputs)
-        h = ctypes.c_void_p()
-        check(lib.gl_prove_device(self.ctx.handle, self.cd.handle, d_wires_ptr, _p(pis), pis.size, ctypes.byref(h)))
-        return Proof(h.value, self.cd.host.n)
+    def prove_device(self, d_wires_ptr, public_inputs, public_inputs_hash=None):
+        return _prove_device(self.ctx, self.cd.handle, self.cd.host.n, d_wires_ptr, public_inputs, public_inputs_hash)
 
     def prove(self, wires, public_inputs):
         wires, pis = _u64(wires), _u64(public_inputs)

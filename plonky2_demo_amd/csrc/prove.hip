@@ -549,14 +549,19 @@ extern "C" int gl_fri_query(gl_fri* f, const uint32_t* x_index, uint32_t num_que
 // ======================================================================================================================
 // prove(): the driver (plonk/prover.rs:102-329) -- the phases above plus the transcript
 // ======================================================================================================================
-static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, bool wires_on_device, const uint64_t* h_pis, size_t npis, gl_proof** out);
+static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, bool wires_on_device, const uint64_t* h_pis, size_t npis, const uint64_t* h_pi_hash, gl_proof** out);
 extern "C" int gl_prove(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, const uint64_t* h_pis, size_t npis, gl_proof** out) {
-    return prove_impl(ctx, cir, h_wires, false, h_pis, npis, out);
+    return prove_impl(ctx, cir, h_wires, false, h_pis, npis, nullptr, out);
 }
 extern "C" int gl_prove_device(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t* h_pis, size_t npis, gl_proof** out) {
-    return prove_impl(ctx, cir, d_wires, true, h_pis, npis, out);
+    return prove_impl(ctx, cir, d_wires, true, h_pis, npis, nullptr, out);
 }
-static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, bool wires_on_device, const uint64_t* h_pis, size_t npis, gl_proof** out) {
+extern "C" int gl_prove_device_hashed(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t* h_pis, size_t npis,
+                                      const uint64_t public_inputs_hash[4], gl_proof** out) {
+    GL_REQUIRE(public_inputs_hash, GL_ERR_ARG, "gl_prove_device_hashed: null hash");
+    return prove_impl(ctx, cir, d_wires, true, h_pis, npis, public_inputs_hash, out);
+}
+static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, bool wires_on_device, const uint64_t* h_pis, size_t npis, const uint64_t* h_pi_hash, gl_proof** out) {
     GL_REQUIRE(ctx && cir && h_wires && h_pis && out, GL_ERR_ARG, "gl_prove: null argument");
     // circuit data is read-only while proving: any context (stream) of the same device may prove against it
     GL_REQUIRE(cir->ctx->device == ctx->device, GL_ERR_ARG, "gl_prove: circuit lives on another device");
@@ -582,7 +587,8 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     BatchHolder wires; GL_TRY(gl_batch_from_device(ctx, d_wires, 135, n, d.rate_bits, d.cap_height, 1, &wires.b));
     // public_inputs_hash (prover.rs:126-127) on the host while the GPU commits
     gl_t pi_hash[4];
-    glhost::host_hash_no_pad(h_pis, npis, pi_hash);
+    if (h_pi_hash) for (int i = 0; i < 4; i++) pi_hash[i] = gl_canon(h_pi_hash[i]);      // the witness generator's sponge already produced it
+    else glhost::host_hash_no_pad(h_pis, npis, pi_hash);
     HostChallenger ch;
     ch.observe_many(cir->circuit_digest, 4);
     ch.observe_many(pi_hash, 4);

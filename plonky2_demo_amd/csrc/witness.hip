@@ -91,7 +91,8 @@ extern "C" int gl_matmul_witgen_create(gl_ctx* ctx, const gl_host_circuit* hc, g
     return GL_OK;
 }
 
-extern "C" int gl_matmul_witgen_run(gl_matmul_witgen* g, const uint64_t* a, const uint64_t* b, uint64_t filler_seed, uint64_t* d_wires, uint64_t* h_pis) {
+extern "C" int gl_matmul_witgen_run(gl_matmul_witgen* g, const uint64_t* a, const uint64_t* b, uint64_t filler_seed, uint64_t* d_wires, uint64_t* h_pis,
+                                    uint64_t* h_pi_hash) {
     GL_REQUIRE(g && a && b && d_wires && h_pis, GL_ERR_ARG, "gl_matmul_witgen_run: null argument");
     gl_ctx* ctx = g->ctx;
     GL_TRY(ctx->activate());
@@ -134,6 +135,7 @@ extern "C" int gl_matmul_witgen_run(gl_matmul_witgen* g, const uint64_t* a, cons
     }
     const size_t r_pi = h.num_poseidon_rows, r_const = r_pi + 1;
     for (int t = 0; t < 4; t++) sp[t * R + r_pi] = state[t];
+    if (h_pi_hash) for (int t = 0; t < 4; t++) h_pi_hash[t] = state[t];          // = hash_no_pad(public inputs) (prover.rs:126-127)
     { uint64_t s = filler_seed; for (size_t c = 4; c < 135; c++) sp[c * R + r_pi] = splitmix64_next(s) % GL_P; }   // circuit_builder.rs:904-910
     sp[0 * R + r_const] = 0; sp[1 * R + r_const] = 1;
 

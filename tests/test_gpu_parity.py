@@ -270,6 +270,8 @@ def test_prove_m64_matches_oracle(gpu, orc):
     gb = gp.to_bytes()
     assert gb == op.to_bytes() and len(gb) == 250756
     assert op.verify()[0]
+    hc = p.MatmulCircuit(64)
+    assert hc.verify(gb, op.c.constants_sigmas_cap, op.c.digest) == (True, "")        # the product's own verify()
 
 
 def test_oracle_verifier_accepts_gpu_proof_bytes(gpu, orc):
@@ -313,6 +315,7 @@ def test_prove_m128_config5(gpu, orc):
     v = orc.circuit(m, verifier_only=True)
     ok, msg = v.verify_bytes(by, cd.constants_sigmas_cap, cd.circuit_digest)
     assert ok, msg
+    assert cd.verify(pr) == (True, "")
     assert len(pr.challenges()["fri_betas"]) == 4
 
 
@@ -434,4 +437,21 @@ def test_device_witness_generation_equals_host(gpu, orc, m):
     # ... and it proves: same bytes as proving the host witness
     if m in (2, 20):
         cd = hc.build()
-        assert cd.prove_device(buf.ptr, dpis).to_bytes() == cd.prove(wires, pis).to_bytes()
+        assert (gen.public_inputs_hash == orc.hash_no_pad(pis)).all()
+        want = cd.prove(wires, pis).to_bytes()
+        assert cd.prove_device(buf.ptr, dpis).to_bytes() == want
+        assert cd.prove_device(buf.ptr, dpis, gen.public_inputs_hash).to_bytes() == want
+
+
+def test_demo_binary_builds_proves_and_verifies(gpu):
+    # examples/matrix_mul: the reference's bin/matrix_mul.rs flow (build, prove, print, verify) in C++ over the C ABI
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "matrix_mul")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    for m, seed in ((2, 7), (20, 11)):
+        r = subprocess.run([exe, str(m), str(seed)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.strip() == "length of proof.public_inputs is %d" % (3 * m * m)      # matrix_mul.rs:90
+        assert "accepted" in r.stderr

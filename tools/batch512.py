@@ -41,7 +41,7 @@ def run(kind):
             a, b = ops[i]
             if kind == "device":
                 pis = gens[lane].run(a, b, bufs[lane].ptr, filler_seed=i)
-                pr = lanes[lane][1].prove_device(bufs[lane].ptr, pis)
+                pr = lanes[lane][1].prove_device(bufs[lane].ptr, pis, gens[lane].public_inputs_hash)
             else:
                 wires, pis = hc.witness(a, b, filler_seed=i)
                 pr = lanes[lane][1].prove(wires, pis)
