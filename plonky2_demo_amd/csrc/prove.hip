@@ -185,7 +185,7 @@ static int partial_products_values(gl_ctx* ctx, const gl_circuit* cir, const gl_
     for (int i = 0; i < 2; i++) { pp.betas[i] = gl_canon(betas[i]); pp.gammas[i] = gl_canon(gammas[i]); }
     pp.n = (uint32_t)n; pp.chunk_prod = d_chunk.as<gl_t>(); pp.row_prod = d_rowp.as<gl_t>();
     ctx->timing_begin("compute partial products");
-    hipLaunchKernelGGL(k_pp_chunk_products, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pp);
+    hipLaunchKernelGGL(k_pp_chunk_products, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, st, pp);
     hipLaunchKernelGGL(k_z_segment_products, dim3(nseg, 2), dim3(256), 0, st, d_rowp.as<gl_t>(), (uint32_t)n, d_seg.as<gl_t>());
     hipLaunchKernelGGL(k_z_segment_scan, dim3(1), dim3(64), 0, st, d_seg.as<gl_t>(), nseg);
     hipLaunchKernelGGL(k_z_finalize, dim3(nseg, 2), dim3(256), 0, st, d_rowp.as<gl_t>(), d_chunk.as<gl_t>(), d_seg.as<gl_t>(), (uint32_t)n, d_zs);
@@ -645,8 +645,17 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
         gl_t* d_open = ctx->dev_small + 4096;
         size_t off = 0;
         ctx->timing_begin("construct the opening set");
-        for (int o = 0; o < 4; o++) { launch_open(ctx, oracles[o], 0, oracles[o]->ncols, zeta, d_open + 2 * off); off += oracles[o]->ncols; }
-        launch_open(ctx, zs.b, 0, 2, gzeta, d_open + 2 * nopen);
+        // zeta^i and (g zeta)^i tabulated once per proof, shared by all polynomials
+        DevBuf d_zpow(ctx); GL_TRY(d_zpow.alloc(4 * n * sizeof(gl_t)));
+        gl_t* zp = d_zpow.as<gl_t>();
+        hipLaunchKernelGGL(k_ext_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, zeta.a, zeta.b, (uint32_t)n, zp, zp + n);
+        hipLaunchKernelGGL(k_ext_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gzeta.a, gzeta.b, (uint32_t)n, zp + 2 * n, zp + 3 * n);
+        for (int o = 0; o < 4; o++) {
+            hipLaunchKernelGGL(k_eval_with_powers, dim3((unsigned)oracles[o]->ncols), dim3(256), 0, st, oracles[o]->coeffs, (uint32_t)n, (uint64_t)n,
+                               zp, zp + n, d_open + 2 * off);
+            off += oracles[o]->ncols;
+        }
+        hipLaunchKernelGGL(k_eval_with_powers, dim3(2), dim3(256), 0, st, zs.b->coeffs, (uint32_t)n, (uint64_t)n, zp + 2 * n, zp + 3 * n, d_open + 2 * nopen);
         ctx->timing_end();
         GL_CHECK_HIP(hipGetLastError());
         std::vector<gl_t> tmp(2 * nopen + 4);

@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void k_pp_chunk_products(GlPermParams p) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
     const gl_t x = glp_pow2level(p.xpow_lo, p.xpow_hi, i);
-#pragma unroll 1
-    for (int a = 0; a < 2; a++) {
+    {
+        const int a = blockIdx.y;                       // one challenge per grid row: twice the waves, half the dependent chain
         const gl_t beta = p.betas[a], gamma = p.gammas[a];
         const gl_t bx = gl_mul(beta, x);
         gl_t nump[GLP_CHUNKS], denp[GLP_CHUNKS];
@@ -331,6 +331,42 @@ __global__ __launch_bounds__(256) void k_eval_at_ext(const gl_t* coeffs, uint32_
     }
     if (lo < n) acc = gl2_mul(acc, gl2_exp(z, lo)); else acc = gl2_make(0, 0);
     sha[t] = acc.a; shb[t] = acc.b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < (uint32_t)s) { sha[t] = gl_add(sha[t], sha[t + s]); shb[t] = gl_add(shb[t], shb[t + s]); }
+        __syncthreads();
+    }
+    if (t == 0) { out[2 * poly] = gl_canon(sha[0]); out[2 * poly + 1] = gl_canon(shb[0]); }
+}
+
+// table of powers of an extension element: out_a[i], out_b[i] = z^i, i < n
+__global__ __launch_bounds__(256) void k_ext_powers(gl_t za, gl_t zb, uint32_t n, gl_t* out_a, gl_t* out_b) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const gl2_t v = gl2_canon(gl2_exp(gl2_make(za, zb), i));
+    out_a[i] = v.a; out_b[i] = v.b;
+}
+// p(z) = sum_i c_i z^i with the powers tabulated once per proof: two base-field multiply-adds per coefficient, coalesced
+// reads (thread t takes i = t, t + 256, ...).  grid = (npolys); block = 256.
+__global__ __launch_bounds__(256) void k_eval_with_powers(const gl_t* coeffs, uint32_t n, uint64_t stride, const gl_t* __restrict__ pa,
+                                                          const gl_t* __restrict__ pb, gl_t* out /* [npolys][2] */) {
+    __shared__ gl_t sha[256], shb[256];
+    const uint32_t poly = blockIdx.x, t = threadIdx.x;
+    const gl_t* c = coeffs + (uint64_t)poly * stride;
+    // four independent accumulator pairs and all loads of a step issued before the arithmetic: the chain is latency-bound otherwise
+    gl_t a0 = 0, b0 = 0, a1 = 0, b1 = 0, a2 = 0, b2 = 0, a3 = 0, b3 = 0;
+    uint32_t i = t;
+    for (; i + 768 < n; i += 1024) {
+        const gl_t c0 = c[i], c1 = c[i + 256], c2 = c[i + 512], c3 = c[i + 768];
+        const gl_t x0 = pa[i], x1 = pa[i + 256], x2 = pa[i + 512], x3 = pa[i + 768];
+        const gl_t y0 = pb[i], y1 = pb[i + 256], y2 = pb[i + 512], y3 = pb[i + 768];
+        a0 = gl_mul_add(a0, c0, x0); b0 = gl_mul_add(b0, c0, y0);
+        a1 = gl_mul_add(a1, c1, x1); b1 = gl_mul_add(b1, c1, y1);
+        a2 = gl_mul_add(a2, c2, x2); b2 = gl_mul_add(b2, c2, y2);
+        a3 = gl_mul_add(a3, c3, x3); b3 = gl_mul_add(b3, c3, y3);
+    }
+    for (; i < n; i += 256) { const gl_t ci = c[i]; a0 = gl_mul_add(a0, ci, pa[i]); b0 = gl_mul_add(b0, ci, pb[i]); }
+    sha[t] = gl_add(gl_add(a0, a1), gl_add(a2, a3)); shb[t] = gl_add(gl_add(b0, b1), gl_add(b2, b3));
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (t < (uint32_t)s) { sha[t] = gl_add(sha[t], sha[t + s]); shb[t] = gl_add(shb[t], shb[t + s]); }
