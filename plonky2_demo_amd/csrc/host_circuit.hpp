@@ -225,16 +225,17 @@ inline void poseidon_row_witness(const gl_t* in12, gl_t* row /* 135, stride `str
     for (int i = 0; i < 12; i++) s[i] = gl_add_c(s[i], POSEIDON_PARTIAL_FIRST_RC[i]);
     {
         gl_t t[12]; t[0] = s[0];
-        for (int c = 1; c < 12; c++) { gl_t acc = 0; for (int r = 1; r < 12; r++) acc = gl_mul_add(acc, s[r], POSEIDON_PARTIAL_INIT[(r - 1) * 11 + (c - 1)]); t[c] = acc; }
+        for (int c = 1; c < 12; c++) { PsdHostDot d; for (int r = 1; r < 12; r++) psd_host_dot_term(d, s[r], POSEIDON_PARTIAL_INIT[(r - 1) * 11 + (c - 1)]); t[c] = psd_host_dot_reduce(d); }
         for (int i = 0; i < 12; i++) s[i] = t[i];
     }
     for (int r = 0; r < POSEIDON_PARTIAL_ROUNDS; r++) {
         row[(PW_PARTIAL + r) * stride] = gl_canon(s[0]);
         gl_t s0 = gl_add_c(psd_sbox(s[0]), POSEIDON_PARTIAL_RC[r]);
-        gl_t dd = gl_mul_small(s0, 25);
-        for (int i = 1; i < 12; i++) dd = gl_mul_add(dd, s[i], POSEIDON_PARTIAL_ROW[r * 11 + i - 1]);
+        PsdHostDot dd;
+        psd_host_dot_term(dd, s0, 25);
+        for (int i = 1; i < 12; i++) psd_host_dot_term(dd, s[i], POSEIDON_PARTIAL_ROW[r * 11 + i - 1]);
         for (int i = 1; i < 12; i++) s[i] = gl_mul_add(s[i], s0, POSEIDON_PARTIAL_COL[r * 11 + i - 1]);
-        s[0] = dd;
+        s[0] = psd_host_dot_reduce(dd);
     }
     round += POSEIDON_PARTIAL_ROUNDS;
     for (int r = 0; r < 4; r++) {

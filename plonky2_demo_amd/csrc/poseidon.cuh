@@ -31,6 +31,18 @@ GL_HD gl_t psd_sbox(gl_t x) {
     return gl_mul(x3, x4);
 }
 
+// Host formulation (the Challenger, public_inputs_hash, the witness generator's sponge rows, the verifier): 64 x 64 -> 128
+// multiplies are native on the CPU, so sums of products are accumulated unreduced in two 128-bit words (the constant is
+// split into 32-bit halves: 12 terms of 64 x 32 bits stay below 2^100) and reduced once -- the dependent chain of a dot
+// product is one reduction instead of twelve.
+typedef unsigned __int128 psd_u128;
+struct PsdHostDot { psd_u128 lo = 0, hi = 0; };
+inline void psd_host_dot_term(PsdHostDot& d, gl_t s, gl_t c) { d.lo += (psd_u128)s * (uint32_t)c; d.hi += (psd_u128)s * (uint32_t)(c >> 32); }
+inline gl_t psd_host_dot_reduce(const PsdHostDot& d) {
+    const gl_t h = gl_reduce128((gl_t)d.hi, (gl_t)(d.hi >> 64));            // hi * 2^32
+    const gl_t h32 = gl_reduce128(h << 32, h >> 32);
+    return gl_add(gl_reduce128((gl_t)d.lo, (gl_t)(d.lo >> 64)), h32);
+}
 GL_HD void psd_mds(gl_t (&s)[12]) {
     const uint32_t circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     uint32_t lo[12], hi[12];
@@ -132,18 +144,19 @@ GL_HD void psd_partial_rounds(gl_t (&s)[12]) {
         gl_t t[12];
         t[0] = s[0];
         for (int c = 1; c < 12; c++) {
-            gl_t acc = 0;
-            for (int r = 1; r < 12; r++) acc = gl_mul_add(acc, s[r], POSEIDON_PARTIAL_INIT[(r - 1) * 11 + (c - 1)]);
-            t[c] = acc;
+            PsdHostDot d;
+            for (int r = 1; r < 12; r++) psd_host_dot_term(d, s[r], POSEIDON_PARTIAL_INIT[(r - 1) * 11 + (c - 1)]);
+            t[c] = psd_host_dot_reduce(d);
         }
         for (int i = 0; i < 12; i++) s[i] = t[i];
     }
     for (int r = 0; r < POSEIDON_PARTIAL_ROUNDS; r++) {
-        gl_t s0 = gl_add_c(psd_sbox(s[0]), POSEIDON_PARTIAL_RC[r]);
-        gl_t d = gl_mul_small(s0, 17 + 8);   // MDS[0][0] = circ[0] + diag[0]
-        for (int i = 1; i < 12; i++) d = gl_mul_add(d, s[i], POSEIDON_PARTIAL_ROW[r * 11 + i - 1]);
+        const gl_t s0 = gl_add_c(psd_sbox(s[0]), POSEIDON_PARTIAL_RC[r]);
+        PsdHostDot d;
+        psd_host_dot_term(d, s0, 17 + 8);    // MDS[0][0] = circ[0] + diag[0]
+        for (int i = 1; i < 12; i++) psd_host_dot_term(d, s[i], POSEIDON_PARTIAL_ROW[r * 11 + i - 1]);
         for (int i = 1; i < 12; i++) s[i] = gl_mul_add(s[i], s0, POSEIDON_PARTIAL_COL[r * 11 + i - 1]);
-        s[0] = d;
+        s[0] = psd_host_dot_reduce(d);
     }
 #endif
 }

@@ -82,3 +82,20 @@ def test_malformed_lengths(orc):
     hc3, oc3, w3 = _case(orc, 3)
     ok, why = hc.verify(w3.prove().to_bytes(), oc.constants_sigmas_cap, oc.digest)
     assert not ok
+
+
+def test_verifier_under_address_and_ub_sanitizers(orc, tmp_path):
+    # gl_verify parses untrusted bytes: its host code is rebuilt with -fsanitize=address,undefined (CPU build; GPU sanitizers
+    # are not available) and fed the valid proof plus 400 mutations (tools/sanitizer/verify_fuzz.cpp)
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hc, oc, w = _case(orc, 8)
+    (tmp_path / "desc.bin").write_bytes(bytes(hc.desc))
+    (tmp_path / "cap.bin").write_bytes(oc.constants_sigmas_cap.tobytes())
+    (tmp_path / "dig.bin").write_bytes(oc.digest.tobytes())
+    (tmp_path / "proof.bin").write_bytes(w.prove(threads=8).to_bytes())
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tools", "sanitizer")])
+    r = subprocess.run([os.path.join(root, "tools", "sanitizer", "verify_fuzz"), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "valid: 0" in r.stdout and "400 rejected, 0 accepted" in r.stdout
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
