@@ -161,17 +161,67 @@ GL_HD void psd_partial_rounds(gl_t (&s)[12]) {
 #endif
 }
 
-GL_HD void psd_permute(gl_t (&s)[12]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
+// GPU formulation of the permutation: the TEXTBOOK round structure (poseidon.rs:573-596 `poseidon_naive`: every round is
+// constants, S-box, full MDS), not the factorised partial rounds.  On gfx950 a 64 x 64 modular multiply costs ~26 VALU
+// instructions while the MDS layer, whose entries are 6-bit constants, is 288 single-instruction multiply-adds plus 12
+// reductions: 22 partial rounds as "one S-box + MDS" are ~15 % fewer instructions than "one S-box + 11 modular
+// multiply-adds + an 11-term dot product" plus the dense 11 x 11 pre-matrix of the factorised form.  The next round's
+// constants ride along as the addend of the first multiply-add of each accumulator, so the constant layer is free.
+// Same function (pinned by the reference's known-answer vectors and by fast == naive in the oracle).
+template <bool WITH_RC>
+GL_HD void psd_mds_then_constants(gl_t (&s)[12], const gl_t* __restrict__ rc) {
+    // the power-of-two entries are made opaque: otherwise the compiler turns x * 16 into a 64-bit shift-add, which needs
+    // the 32-bit operand zero-extended into a register pair first (two extra moves per term); a multiply-add does not
+    uint32_t k16 = 16, k2 = 2, k8 = 8;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(k16), "+s"(k2), "+s"(k8));
 #endif
+    const uint32_t circ[12] = {17, 15, 41, k16, k2, 28, 13, 13, 39, 18, 34, 20};
+    uint32_t lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { lo[i] = (uint32_t)s[i]; hi[i] = (uint32_t)(s[i] >> 32); }
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        gl_t al = 0, ah = 0;   // each < (256 + 8 + 1) * 2^32 < 2^41
+        if (WITH_RC) { const gl_t c = rc[r]; al = (uint32_t)c; ah = c >> 32; }
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            al += (gl_t)lo[(i + r) % 12] * circ[i];
+            ah += (gl_t)hi[(i + r) % 12] * circ[i];
+        }
+        if (r == 0) { al += (gl_t)lo[0] * k8; ah += (gl_t)hi[0] * k8; }   // MDS_MATRIX_DIAG[0] = 8
+        // al + ah 2^32 as a 96-bit number, in 32-bit pieces so that no 64-bit register pair has to be rebuilt
+        const uint32_t al_hi = (uint32_t)(al >> 32), ah_lo = (uint32_t)ah;
+        const uint32_t mid = al_hi + ah_lo;
+        const uint32_t top = (uint32_t)(ah >> 32) + (mid < ah_lo ? 1u : 0u);
+        s[r] = gl_reduce96(((gl_t)mid << 32) | (uint32_t)al, top);
+    }
+}
+GL_HD void psd_sbox_all(gl_t (&s)[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = psd_sbox(s[i]);
+}
+GL_HD void psd_permute(gl_t (&s)[12]) {       // (host + device only so that host code parses in the device pass)
+    const gl_t* __restrict__ rc = d_POSEIDON_RC;
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add_c(s[i], rc[i]);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) { psd_sbox_all(s); psd_mds_then_constants<true>(s, rc + 12 * (r + 1)); }
+#pragma unroll 1
+    for (int r = 4; r < 4 + POSEIDON_PARTIAL_ROUNDS; r++) { s[0] = psd_sbox(s[0]); psd_mds_then_constants<true>(s, rc + 12 * (r + 1)); }
+#pragma unroll 1
+    for (int r = 4 + POSEIDON_PARTIAL_ROUNDS; r < 7 + POSEIDON_PARTIAL_ROUNDS; r++) { psd_sbox_all(s); psd_mds_then_constants<true>(s, rc + 12 * (r + 1)); }
+    psd_sbox_all(s);
+    psd_mds_then_constants<false>(s, nullptr);
+}
+#else
+GL_HD void psd_permute(gl_t (&s)[12]) {         // host formulation (GL_HD only so that kernels parse in the host pass)
     for (int r = 0; r < 4; r++) psd_full_round(s, r);
     psd_partial_rounds(s);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
     for (int r = 0; r < 4; r++) psd_full_round(s, 4 + POSEIDON_PARTIAL_ROUNDS + r);
 }
+#endif
 
 // two_to_one (hashing.rs:98-115): permute([l, r, 0,0,0,0])[0..4]
 GL_HD void psd_two_to_one(const gl_t* l, const gl_t* r, gl_t* out) {
