@@ -3,10 +3,12 @@
 // plonky2/src/hash/poseidon_goldilocks.rs:449-485); the sponge / compression wrappers follow
 // plonky2/src/hash/hashing.rs:98-146 and plonky2/src/plonk/config.rs:55-66.
 //
-// One lane owns one 12-word state (24 VGPRs).  The MDS layer exploits the 6-bit circulant entries:
-// every state word is split into 32-bit halves and the two 12-term dot products are accumulated in
-// 64-bit registers without intermediate reduction (v_mad_u64_u32 with SGPR constants), followed by
+// GPU (psd_permute under __HIP_DEVICE_COMPILE__): one lane owns one 12-word state (24 VGPRs) and runs the textbook round
+// structure; the MDS layer exploits the 6-bit circulant entries: every state word is split into 32-bit halves and the two
+// 12-term dot products are accumulated in 64-bit registers without intermediate reduction (v_mad_u64_u32), followed by
 // one 96-bit reduction per output word -- the same lazy-reduction idea as poseidon.rs:176-198.
+// Host (Challenger, public_inputs_hash, witness rows, verifier): the factorised "fast" partial rounds of
+// poseidon.rs:311-366,399-427 with 128-bit lazy dot products; its tables are derived by tools/gen_poseidon_constants.py.
 #pragma once
 #include "gl64.cuh"
 #include "poseidon_constants.h"
@@ -14,10 +16,8 @@
 #if defined(__HIPCC__)
 // device copies of the tables (per translation unit, constant address space -> scalar loads)
 #define POSEIDON_TABLE(name, n) static __constant__ const uint64_t d_##name[n]
-#define POSEIDON_TABLE32(name, n) static __constant__ const uint32_t d_##name[n]
 #include "poseidon_constants.inc"
 #undef POSEIDON_TABLE
-#undef POSEIDON_TABLE32
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -73,73 +73,9 @@ GL_HD void psd_full_round(gl_t (&s)[12], int round) {
     psd_mds(s);
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-// Carry-free dot products for the GPU: every 64-bit table constant is split into 22-bit limbs (c = l0 + l1 2^22 +
-// l2 2^44) and every state word into 32-bit halves, so that the six partial sums
-//   A0 = sum lo*l0, A1 = sum lo*l1, A2 = sum lo*l2, A3 = sum hi*l0, A4 = sum hi*l1, A5 = sum hi*l2     (each < 12 * 2^54)
-// fit 64-bit registers and are accumulated by plain v_mad_u64_u32 with scalar constants -- no carries, no
-// reduction per term.  value = A0 + A1 2^22 + A2 2^44 + (A3 + A4 2^22 + A5 2^44) 2^32, reduced once.
-struct PsdDot { gl_t a0, a1, a2, a3, a4, a5; };
-__device__ __forceinline__ void psd_dot_term(PsdDot& d, gl_t s, const uint32_t* __restrict__ limbs) {
-    const uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
-    const uint32_t l0 = limbs[0], l1 = limbs[1], l2 = limbs[2];
-    d.a0 += (gl_t)lo * l0; d.a1 += (gl_t)lo * l1; d.a2 += (gl_t)lo * l2;
-    d.a3 += (gl_t)hi * l0; d.a4 += (gl_t)hi * l1; d.a5 += (gl_t)hi * l2;
-}
-// a + (b << 22) + (c << 44) as a 128-bit number (a, b, c < 2^58)
-__device__ __forceinline__ void psd_dot_fold3(gl_t a, gl_t b, gl_t c, gl_t& lo, gl_t& hi) {
-    gl_t l = a + (b << 22);
-    gl_t h = (b >> 42) + ((l < a) ? 1 : 0);
-    gl_t l2 = l + (c << 44);
-    h += (c >> 20) + ((l2 < l) ? 1 : 0);
-    lo = l2; hi = h;
-}
-__device__ __forceinline__ gl_t psd_dot_reduce(const PsdDot& d) {
-    gl_t lo0, hi0, lo1, hi1;
-    psd_dot_fold3(d.a0, d.a1, d.a2, lo0, hi0);        // hi0 < 2^39
-    psd_dot_fold3(d.a3, d.a4, d.a5, lo1, hi1);        // hi1 < 2^39
-    // V = lo0 + hi0 2^64 + (lo1 + hi1 2^64) 2^32,  2^96 = -1 (mod p)
-    gl_t x = lo0 + (lo1 << 32);
-    gl_t h = hi0 + (lo1 >> 32) + ((x < lo0) ? 1 : 0);    // < 2^41
-    gl_t r = gl_reduce128(x, h);
-    return gl_sub_c(r, hi1);                              // hi1 is canonical (< 2^39)
-}
-#endif
-
 GL_HD void psd_partial_rounds(gl_t (&s)[12]) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl_add_c(s[i], PSD_TAB(POSEIDON_PARTIAL_FIRST_RC)[i]);
-#if defined(__HIP_DEVICE_COMPILE__)
-    {   // dense 11x11 pre-matrix: one dot product per output word, looped to keep the scalar constants few
-        gl_t t[12];
-        t[0] = s[0];
-#pragma unroll 1
-        for (int c = 1; c < 12; c++) {
-            PsdDot d = {0, 0, 0, 0, 0, 0};
-            const uint32_t* lm = d_POSEIDON_PARTIAL_INIT_T_LIMBS + (c - 1) * 33;
-#pragma unroll
-            for (int r = 1; r < 12; r++) psd_dot_term(d, s[r], lm + 3 * (r - 1));
-            const gl_t v = psd_dot_reduce(d);
-            // scatter into t[c] without dynamic register indexing
-#pragma unroll
-            for (int k = 1; k < 12; k++) if (k == c) t[k] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = t[i];
-    }
-#pragma unroll 1
-    for (int r = 0; r < POSEIDON_PARTIAL_ROUNDS; r++) {
-        const gl_t s0 = gl_add_c(psd_sbox(s[0]), d_POSEIDON_PARTIAL_RC[r]);
-        PsdDot d = {0, 0, 0, 0, 0, 0};
-        d.a0 = (gl_t)(uint32_t)s0 * 25u; d.a3 = (gl_t)(uint32_t)(s0 >> 32) * 25u;      // MDS[0][0] = circ[0] + diag[0] = 25
-        const uint32_t* lm = d_POSEIDON_PARTIAL_ROW_LIMBS + r * 33;
-#pragma unroll
-        for (int i = 1; i < 12; i++) psd_dot_term(d, s[i], lm + 3 * (i - 1));
-#pragma unroll
-        for (int i = 1; i < 12; i++) s[i] = gl_mul_add(s[i], s0, d_POSEIDON_PARTIAL_COL[r * 11 + i - 1]);
-        s[0] = psd_dot_reduce(d);
-    }
-#else
     {
         gl_t t[12];
         t[0] = s[0];
@@ -158,10 +94,8 @@ GL_HD void psd_partial_rounds(gl_t (&s)[12]) {
         for (int i = 1; i < 12; i++) s[i] = gl_mul_add(s[i], s0, POSEIDON_PARTIAL_COL[r * 11 + i - 1]);
         s[0] = psd_host_dot_reduce(d);
     }
-#endif
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
 // GPU formulation of the permutation: the TEXTBOOK round structure (poseidon.rs:573-596 `poseidon_naive`: every round is
 // constants, S-box, full MDS), not the factorised partial rounds.  On gfx950 a 64 x 64 modular multiply costs ~26 VALU
 // instructions while the MDS layer, whose entries are 6-bit constants, is 288 single-instruction multiply-adds plus 12
@@ -202,6 +136,7 @@ GL_HD void psd_sbox_all(gl_t (&s)[12]) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = psd_sbox(s[i]);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
 GL_HD void psd_permute(gl_t (&s)[12]) {       // (host + device only so that host code parses in the device pass)
     const gl_t* __restrict__ rc = d_POSEIDON_RC;
 #pragma unroll

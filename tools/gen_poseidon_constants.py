@@ -176,15 +176,7 @@ def emit(path, rc, T):
         out.append("};")
         return "\n".join(out)
 
-    def arr32(name, vals, per_line=9):
-        out = ["POSEIDON_TABLE32(%s, %d) = {" % (name, len(vals))]
-        for i in range(0, len(vals), per_line):
-            out.append("    " + ", ".join("0x%06xu" % v for v in vals[i:i + per_line]) + ",")
-        out.append("};")
-        return "\n".join(out)
-
     flat = lambda rows: [x for row in rows for x in row]
-    limbs = lambda vals: [l for v in vals for l in (v & 0x3FFFFF, (v >> 22) & 0x3FFFFF, v >> 44)]
     inc = [
         "// GENERATED by tools/gen_poseidon_constants.py -- do not edit.",
         "// Poseidon over Goldilocks, width 12, rate 8, x^7, 4+22+4 rounds.",
@@ -204,10 +196,6 @@ def emit(path, rc, T):
         arr("POSEIDON_PARTIAL_ROW", flat(T["rows_v"])),
         "// per partial round: out[i] = s[i] + s0*COL[r][i-1]",
         arr("POSEIDON_PARTIAL_COL", flat(T["cols_w"])),
-        "// the same INIT (transposed: [out-1][in-1]) and ROW tables split into 22-bit limbs (c = l0 + l1*2^22 + l2*2^44),",
-        "// so that a 11-term dot product can be accumulated in six 64-bit registers without carries (GPU path)",
-        arr32("POSEIDON_PARTIAL_INIT_T_LIMBS", limbs(flat([[T["init"][c][r] for r in range(W - 1)] for c in range(W - 1)]))),
-        arr32("POSEIDON_PARTIAL_ROW_LIMBS", limbs(flat(T["rows_v"]))),
         "",
     ]
     inc_path = path[:-2] + ".inc" if path.endswith(".h") else path + ".inc"
@@ -222,10 +210,8 @@ def emit(path, rc, T):
         "#define POSEIDON_HALF_FULL_ROUNDS 4",
         "#define POSEIDON_PARTIAL_ROUNDS 22",
         "#define POSEIDON_TABLE(name, n) static const uint64_t name[n]",
-        "#define POSEIDON_TABLE32(name, n) static const uint32_t name[n]",
         '#include "%s"' % os.path.basename(inc_path),
         "#undef POSEIDON_TABLE",
-        "#undef POSEIDON_TABLE32",
         "",
     ]
     with open(path, "w") as f:
