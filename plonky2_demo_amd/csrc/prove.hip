@@ -240,7 +240,10 @@ static int quotient_chunks(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* w
     q.next_step = 1u << d.rate_bits;
     for (unsigned g = 0; g < d.num_gates; g++) { q.gate_types[g] = d.gate_types[g]; q.gate_sel[g] = d.gate_selector_index[g]; q.group_start[g] = d.gate_group_start[g]; q.group_end[g] = d.gate_group_end[g]; }
     ctx->timing_begin("compute quotient polys");
-    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
+    hipLaunchKernelGGL(k_quotient<false>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
+    bool has_poseidon_gate = false;
+    for (unsigned g = 0; g < d.num_gates; g++) has_poseidon_gate |= d.gate_types[g] == 4;
+    if (has_poseidon_gate) hipLaunchKernelGGL(k_quotient<true>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
     ctx->timing_end();
     GL_CHECK_HIP(hipGetLastError());
     // coset_ifft(7) of each quotient (prover.rs:739-743); the 8n coefficients ARE the 8 chunks of n (prover.rs:245-258)

@@ -166,88 +166,87 @@ struct GlAlphaAcc {
     }
 };
 
-// PoseidonGate constraints (gates/poseidon.rs:193-272), term index base `t0`, streamed wire reads
+// PoseidonGate constraints (gates/poseidon.rs:193-272), term index base `t0`.  Wire k of the point lives at w[k * N]; the
+// wires are read through WALKING pointers (p += N) in the order the gate consumes them: with closed-form addresses the
+// compiler hoists all 135 loop-invariant 64-bit addresses out of the gate loop and the kernel needs ~290 VGPRs.
+// Textbook round structure (constants, S-box, MDS) with the next round's constants folded into the MDS accumulators
+// (psd_mds_then_constants): the wire holding an S-box input is compared with the state right after the constants, which is
+// the same value in every factorisation of the partial rounds (gates/poseidon.rs:139-189).
+// advance a wire pointer and hide the result from the optimiser, so that the addresses of later wires cannot be formed
+// (and kept in registers) ahead of time
+__device__ __forceinline__ const gl_t* glq_step(const gl_t* p, size_t stride) {
+    p += stride;
+    asm volatile("" : "+v"(p));
+    return p;
+}
 __device__ __forceinline__ void glq_poseidon_gate(const gl_t* __restrict__ w, size_t N, GlAlphaAcc& acc, uint32_t t0) {
     uint32_t t = t0;
-    const gl_t swap = w[24 * N];
-    acc.add(t++, gl_mul(swap, gl_sub(swap, 1)));
     gl_t s[12];
+    {
+        const gl_t* wp = w;                              // wires 0..11: inputs
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const gl_t lhs = w[(size_t)i * N], rhs = w[(size_t)(i + 4) * N], delta = w[(size_t)(25 + i) * N];
-        acc.add(t++, gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), delta));
-        s[i] = gl_add(lhs, delta);
-        s[i + 4] = gl_sub(rhs, delta);
+        for (int i = 0; i < 12; i++) { s[i] = *wp; wp = glq_step(wp, N); }
+        wp = glq_step(wp, 12 * N);                                    // skip the outputs (12..23)
+        const gl_t swap = *wp; wp = glq_step(wp, N);                  // 24
+        acc.add(t++, gl_mul(swap, gl_sub(swap, 1)));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                    // 25..28: delta_i = swap * (rhs - lhs)
+            const gl_t delta = *wp; wp = glq_step(wp, N);
+            const gl_t lhs = s[i], rhs = s[i + 4];
+            acc.add(t++, gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), delta));
+            s[i] = gl_add(lhs, delta);
+            s[i + 4] = gl_sub(rhs, delta);
+        }
     }
+    const gl_t* __restrict__ rc = d_POSEIDON_RC;
 #pragma unroll
-    for (int i = 8; i < 12; i++) s[i] = w[(size_t)i * N];
-    int round = 0;
+    for (int i = 0; i < 12; i++) s[i] = gl_add_c(s[i], rc[i]);
+    const gl_t* wp = w + 29 * N;                         // 29..64: S-box inputs of full rounds 1..3
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl_add_c(s[i], d_POSEIDON_RC[12 * round + i]);
         if (r != 0) {
 #pragma unroll
-            for (int i = 0; i < 12; i++) { const gl_t in = w[(size_t)(29 + 12 * (r - 1) + i) * N]; acc.add(t++, gl_sub(s[i], in)); s[i] = in; }
+            for (int i = 0; i < 12; i++) { const gl_t in = *wp; wp = glq_step(wp, N); acc.add(t++, gl_sub(s[i], in)); s[i] = in; }
         }
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = psd_sbox(s[i]);
-        psd_mds(s);
-        round++;
-    }
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add_c(s[i], d_POSEIDON_PARTIAL_FIRST_RC[i]);
-    {
-        gl_t tmp[12];
-        tmp[0] = s[0];
-#pragma unroll
-        for (int c = 1; c < 12; c++) {
-            gl_t a2 = 0;
-#pragma unroll
-            for (int r = 1; r < 12; r++) a2 = gl_mul_add(a2, s[r], d_POSEIDON_PARTIAL_INIT[(r - 1) * 11 + (c - 1)]);
-            tmp[c] = a2;
-        }
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = tmp[i];
+        psd_sbox_all(s);
+        psd_mds_then_constants<true>(s, rc + 12 * (r + 1));
     }
 #pragma unroll 1
-    for (int r = 0; r < POSEIDON_PARTIAL_ROUNDS; r++) {
-        const gl_t in = w[(size_t)(65 + r) * N];
+    for (int r = 0; r < POSEIDON_PARTIAL_ROUNDS; r++) {  // 65..86
+        const gl_t in = *wp; wp = glq_step(wp, N);
         acc.add(t++, gl_sub(s[0], in));
-        const gl_t s0 = gl_add_c(psd_sbox(in), d_POSEIDON_PARTIAL_RC[r]);
-        gl_t dd = gl_mul_small(s0, 25);
-#pragma unroll
-        for (int i = 1; i < 12; i++) dd = gl_mul_add(dd, s[i], d_POSEIDON_PARTIAL_ROW[r * 11 + i - 1]);
-#pragma unroll
-        for (int i = 1; i < 12; i++) s[i] = gl_mul_add(s[i], s0, d_POSEIDON_PARTIAL_COL[r * 11 + i - 1]);
-        s[0] = dd;
+        s[0] = psd_sbox(in);
+        psd_mds_then_constants<true>(s, rc + 12 * (4 + r + 1));
     }
-    round += POSEIDON_PARTIAL_ROUNDS;
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 4; r++) {                        // 87..134
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl_add_c(s[i], d_POSEIDON_RC[12 * round + i]);
-#pragma unroll
-        for (int i = 0; i < 12; i++) { const gl_t in = w[(size_t)(87 + 12 * r + i) * N]; acc.add(t++, gl_sub(s[i], in)); s[i] = in; }
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = psd_sbox(s[i]);
-        psd_mds(s);
-        round++;
+        for (int i = 0; i < 12; i++) { const gl_t in = *wp; wp = glq_step(wp, N); acc.add(t++, gl_sub(s[i], in)); s[i] = in; }
+        psd_sbox_all(s);
+        if (r < 3) psd_mds_then_constants<true>(s, rc + 12 * (4 + POSEIDON_PARTIAL_ROUNDS + r + 1));
+        else psd_mds_then_constants<false>(s, nullptr);
     }
+    wp = w + 12 * N;                                     // 12..23: outputs
 #pragma unroll
-    for (int i = 0; i < 12; i++) acc.add(t++, gl_sub(s[i], w[(size_t)(12 + i) * N]));
+    for (int i = 0; i < 12; i++) { acc.add(t++, gl_sub(s[i], *wp)); wp = glq_step(wp, N); }
 }
 
-__global__ __launch_bounds__(256) void k_quotient(GlQuotParams p) {
+// The vanishing combination is a sum over terms, so it is evaluated by two launches with very different register needs
+// (the PoseidonGate re-runs a permutation; everything else streams wires): POSEIDON_PART = false writes every term except
+// the PoseidonGate's, POSEIDON_PART = true adds the PoseidonGate's filtered constraint sum to it.
+// (at least 3 waves per SIMD: the PoseidonGate part otherwise takes 235 VGPRs for a 5 % slower kernel)
+template <bool POSEIDON_PART>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_quotient(GlQuotParams p) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t N = size_t(1) << p.lgN;
     if (i >= N) return;
-    const gl_t x = glp_pow2level(p.xpow_lo, p.xpow_hi, i);          // 7 * w^i
     const gl_t* w = p.wires + i;
     const gl_t* cs = p.cs + i;
     const gl_t* zs = p.zs + i;
-    const uint32_t i_next = (i + p.next_step) & (uint32_t)(N - 1);
     GlAlphaAcc total; total.s0 = 0; total.s1 = 0; total.ap = p.alpha_pows;
+    if constexpr (!POSEIDON_PART) {
+    const gl_t x = glp_pow2level(p.xpow_lo, p.xpow_hi, i);          // 7 * w^i
+    const uint32_t i_next = (i + p.next_step) & (uint32_t)(N - 1);
     // L_0(x) (Z(x) - 1)            (vanishing_poly.rs:263-268; zero_poly_coset.rs:55-60)
     const gl_t l0 = gl_mul(p.zh_evals[i & 7], gl_inv(gl_mul(p.n_field, gl_sub(x, 1))));
     total.add(0, gl_mul(l0, gl_sub(zs[0], 1)));
@@ -275,17 +274,20 @@ __global__ __launch_bounds__(256) void k_quotient(GlQuotParams p) {
             prev0 = next0; prev1 = next1;
         }
     }
+    }
     // gate constraints: sum_g filter_g * sum_j alpha^(22+j) c_{g,j}   (vanishing_poly.rs:706-732, gate.rs:121-146)
     const uint32_t T0 = 2 + 2 * GLP_CHUNKS;
     const gl_t* gc = cs + (size_t)p.num_selectors * N;              // the gate's own constants
 #pragma unroll 1
     for (uint32_t g = 0; g < p.num_gates; g++) {
+        if ((p.gate_types[g] == 4) != POSEIDON_PART) continue;
         const gl_t sel = cs[(size_t)p.gate_sel[g] * N];
         gl_t filter = 1;                                            // gate.rs:277-284
         for (uint32_t k = p.group_start[g]; k < p.group_end[g]; k++) if (k != g) filter = gl_mul(filter, gl_sub((gl_t)k, sel));
         if (p.num_selectors > 1) filter = gl_mul(filter, gl_sub((gl_t)0xFFFFFFFFull, sel));
         GlAlphaAcc acc; acc.s0 = 0; acc.s1 = 0; acc.ap = p.alpha_pows;
-        switch (p.gate_types[g]) {
+        if constexpr (POSEIDON_PART) glq_poseidon_gate(w, N, acc, T0);
+        else switch (p.gate_types[g]) {
             case 1:     // ConstantGate (gates/constant.rs:59-66)
                 acc.add(T0, gl_sub(gc[0], w[0]));
                 acc.add(T0 + 1, gl_sub(gc[N], w[N]));
@@ -304,15 +306,19 @@ __global__ __launch_bounds__(256) void k_quotient(GlQuotParams p) {
                 }
                 break;
             }
-            case 4: glq_poseidon_gate(w, N, acc, T0); break;
             default: break;   // NoopGate
         }
         total.s0 = gl_mul_add(total.s0, filter, acc.s0);
         total.s1 = gl_mul_add(total.s1, filter, acc.s1);
     }
     const gl_t zi = p.zh_inv[i & 7];
-    p.out[i] = gl_canon(gl_mul(total.s0, zi));
-    p.out[N + i] = gl_canon(gl_mul(total.s1, zi));
+    if constexpr (POSEIDON_PART) {
+        p.out[i] = gl_canon(gl_mul_add(p.out[i], total.s0, zi));
+        p.out[N + i] = gl_canon(gl_mul_add(p.out[N + i], total.s1, zi));
+    } else {
+        p.out[i] = gl_canon(gl_mul(total.s0, zi));
+        p.out[N + i] = gl_canon(gl_mul(total.s1, zi));
+    }
 }
 
 // ---- openings: p(z) in F_p^2 for `npolys` base polynomials of n coefficients ---------------------------------------
