@@ -66,11 +66,11 @@ __device__ __forceinline__ void ntt_small_dft(gl_t* u) {
             for (int i = 0; i < s; i++) {
                 gl_t a = u[b + i], c = u[b + i + s];
                 u[b + i] = gl_add(a, c);
-                gl_t d = gl_sub(a, c);
-                // w_{2s}^i = 2^(39 * (32/s) * i)
+                // w_{2s}^i = 2^(39 * (32/s) * i); 2^96 = -1, so a twiddle -2^k is applied as (c - a) * 2^k: no negation
                 unsigned e = (39u * (32u / (unsigned)s) * (unsigned)i) % 192u;
                 if (INV) e = (192u - e) % 192u;
-                u[b + i + s] = gl_mul_2exp(d, e);
+                const gl_t d = (e >= 96u) ? gl_sub(c, a) : gl_sub(a, c);
+                u[b + i + s] = gl_mul_2exp(d, e % 96u);
             }
         }
     }
