@@ -82,21 +82,23 @@ __device__ __forceinline__ gl_t ntt_pow2level(const gl_t* lo, const gl_t* hi, ui
 }
 
 // ---- LDS tile layout --------------------------------------------------------------------------------
-// LOGL <= 10 ("wave-owned"): the tile holds T columns of L points, column-major: lds[t * LW + phi(i)].
+// LOGL <= 10 ("wave-owned"): the tile holds T columns of L points, column-major: lds[t * LW + phi(i)], phi(i) = i + i/16.
 // One wave (64 lanes x 16 elements) owns 1024/L whole columns, so all radix stages of a column are
 // wave-local: they need no workgroup barrier, only program order (LDS executes a wave's accesses in
-// order) and a compiler-level wave barrier.  phi() XORs the low four index bits with the next four so that
-// the stride-16 writes of the first radix-16 stage hit 16 different banks.
+// order) and a compiler-level wave barrier.  phi() pads one element per 16 so that the stride-16 writes of the first
+// radix-16 stage hit 32 different bank pairs (stride 17), and -- unlike an XOR swizzle -- it is additive over the index
+// pieces a stage uses (task base + r * 2^k with k >= 4, or 16 j + o): every LDS access of an unrolled stage is
+// "one base register + immediate offset", no per-element address arithmetic.
 // LOGL > 10: columns span several waves: layout lds[i * (T+1) + t] with workgroup barriers per stage.
 template <int LOGL>
 struct NttGeom {
     static constexpr int LOGT = NTT_TILE_LOG - LOGL, T = 1 << LOGT, L = 1 << LOGL;
     static constexpr bool WAVE_OWNED = (LOGL <= 10);
-    static constexpr int LW = L + (LOGL >= 4 ? (T == 8 ? 2 : 1) : 0);         // column stride (elements)
+    static constexpr int LW = L + (L >> 4) + (T >= 32 ? 1 : 32 / T);           // column stride (elements), see at()
     static constexpr int LDT = T + 1;                                          // row stride of the legacy layout
     static constexpr size_t LDS_BYTES = WAVE_OWNED ? (size_t)T * LW * 8 : (size_t)L * LDT * 8;
     __device__ static __forceinline__ int at(int t, int i) {
-        if constexpr (WAVE_OWNED) return t * LW + (i ^ ((i >> 4) & 15));
+        if constexpr (WAVE_OWNED) return t * LW + i + (i >> 4);
         else return i * LDT + t;
     }
 };
