@@ -36,6 +36,8 @@ struct NttPassParams {
     uint32_t n_in;                     // valid input elements per polynomial (rest read as zero)
     const gl_t* tw_local;              // w_4096^e (direction-specific), 4096 entries
     const gl_t* tw_lo; const gl_t* tw_hi;      // pass twiddle w_N^e, two-level (column pass)
+    const gl_t* tw_pass;                       // or, when non-null, the table w_N^(i2*k1) laid out like the column pass's
+                                               // output ([k1][i2]): one coalesced load instead of two lookups and a multiply
     const gl_t* pre_lo; const gl_t* pre_hi;    // optional input scale by s^i (two-level), or null
     const gl_t* post_lo; const gl_t* post_hi;  // optional output scale by c*s^k (two-level), or null
     gl_t post_const;                   // scalar output factor when post tables are null (1 = none)
@@ -202,8 +204,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_col_pass(NttPassParams p) {
         const uint32_t t = e & (T - 1), k1 = e >> LOGT;
         const uint32_t i2 = c0 + t;
         gl_t x = lds[G::at(t, k1)];
-        x = gl_mul(x, ntt_pow2level(p.tw_lo, p.tw_hi, i2 * k1));
-        if (!NTT_DBG(p, 4) || x == 12345) dst[((uint64_t)k1 << lgN2) + i2] = x;
+        const uint64_t o = ((uint64_t)k1 << lgN2) + i2;
+        x = gl_mul(x, p.tw_pass ? p.tw_pass[o] : ntt_pow2level(p.tw_lo, p.tw_hi, i2 * k1));
+        if (!NTT_DBG(p, 4) || x == 12345) dst[o] = x;
     }
 }
 
@@ -283,6 +286,13 @@ __global__ void ntt_power_table(gl_t base, gl_t scale, gl_t* out_lo, gl_t* out_h
     const uint32_t lo_len = 1u << NTT_SPLIT_LOG;
     if (j < lo_len) out_lo[j] = gl_canon(gl_exp(base, j));
     if (j < hi_len) out_hi[j] = gl_canon(gl_mul(scale, gl_exp(base, (uint64_t)j << NTT_SPLIT_LOG)));
+}
+// out[(k1 << lgN2) + i2] = base^(i2 * k1): the inter-pass twiddles in the order the column pass stores its output
+__global__ void ntt_pass_table(gl_t base, gl_t* out, uint32_t lgN1, uint32_t lgN2) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (1u << (lgN1 + lgN2))) return;
+    const uint32_t k1 = j >> lgN2, i2 = j & ((1u << lgN2) - 1);
+    out[j] = gl_canon(gl_exp(base, (uint64_t)i2 * k1));
 }
 __global__ void ntt_root_table(gl_t base, gl_t* out, uint32_t len) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;

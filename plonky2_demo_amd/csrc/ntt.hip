@@ -63,6 +63,20 @@ int gl_ctx::get_pow_table(gl_t base, gl_t scale, uint32_t hi_len, GlPowTable* ou
     return GL_OK;
 }
 
+int gl_ctx::get_pass_table(gl_t w, uint32_t lgN1, uint32_t lgN2, const gl_t** out) {
+    auto key = std::make_pair(w, lgN1);
+    auto it = pass_tables.find(key);
+    if (it != pass_tables.end()) { *out = it->second; return GL_OK; }
+    const size_t N = size_t(1) << (lgN1 + lgN2);
+    gl_t* t = nullptr;
+    GL_CHECK_HIP(hipMalloc((void**)&t, N * sizeof(gl_t)));
+    hipLaunchKernelGGL(ntt_pass_table, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w, t, lgN1, lgN2);
+    GL_CHECK_HIP(hipGetLastError());
+    pass_tables[key] = t;
+    *out = t;
+    return GL_OK;
+}
+
 int gl_ctx::pool_alloc(size_t bytes, void** out) {
     const size_t gran = bytes >= (size_t(1) << 20) ? (size_t(1) << 20) : (size_t(1) << 12);
     const size_t want = ((bytes ? bytes : 8) + gran - 1) / gran * gran;
@@ -205,6 +219,7 @@ extern "C" void gl_ctx_destroy(gl_ctx* c) {
     c->pool_trim();
     for (auto& kv : c->pool_block_size) (void)hipFree(kv.first);      // blocks still held by live handles
     for (auto& kv : c->pow_tables) (void)hipFree(kv.second.lo);
+    for (auto& kv : c->pass_tables) (void)hipFree(kv.second);
     for (auto& kv : c->offset_tables) (void)hipFree(kv.second);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -341,6 +356,10 @@ int gl_ntt_run(gl_ctx* c, const gl_t* src, uint64_t src_stride, uint32_t n_in, g
     gl_t w = gl_host_root_of_unity(lgN);
     if (inverse) w = gl_canon(gl_inv(w));
     GL_TRY(c->get_pow_table(w, 1, (uint32_t)(N >> NTT_SPLIT_LOG), &tw));
+    // the N inter-pass twiddles as a table in output order (8 N bytes, shared by every polynomial of every batch): worth it
+    // when several polynomials share it
+    const gl_t* tw_pass = nullptr;
+    if (lgN <= 22 && batch >= 4) GL_TRY(c->get_pass_table(w, lgN1, lgN2, &tw_pass));
     size_t want = c->scratch_target > N ? c->scratch_target : N;
     if (want > (size_t)batch * N) want = (size_t)batch * N;
     GL_TRY(c->ensure_scratch(want));
@@ -352,7 +371,7 @@ int gl_ntt_run(gl_ctx* c, const gl_t* src, uint64_t src_stride, uint32_t n_in, g
         a.src = src + (uint64_t)b0 * src_stride; a.src_stride = src_stride;
         a.dst = c->scratch; a.dst_stride = N;
         a.batch = nb; a.lgN1 = lgN1; a.lgN2 = lgN2; a.n_in = n_in;
-        a.tw_lo = tw.lo; a.tw_hi = tw.hi;
+        a.tw_lo = tw.lo; a.tw_hi = tw.hi; a.tw_pass = tw_pass;
         if (pre_shift) { a.pre_lo = pre.lo; a.pre_hi = pre.hi; }
         GL_TRY(dispatch_col(c, (int)lgN1, inverse, a, dim3((1u << lgN2) / TA, nb)));
         NttPassParams r = p;
