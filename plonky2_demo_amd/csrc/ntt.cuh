@@ -113,7 +113,10 @@ __device__ __forceinline__ void ntt_wave_sync() {
 }
 
 // All Stockham stages over the tile in LDS: L = 2^LOGL points per column, Ns = 2^LOGNS already combined.
-template <int LOGL, int LOGNS, bool INV>
+// ZP ("zero padded", column pass of an LDE with rate >= 8): only the first L/8 points of every column are non-zero, so
+// of the R inputs i = j + r L/R of a first-stage task only r < R/8 exist: a radix-8 first stage is a broadcast, a radix-16
+// one is x0 + w_16^o x1.  The zero points are neither stored to nor read from LDS.
+template <int LOGL, int LOGNS, bool INV, bool ZP = false>
 __device__ __forceinline__ void ntt_lds_stages(gl_t* lds, const gl_t* __restrict__ tw_local, int tid) {
     if constexpr (LOGNS < LOGL) {
         using G = NttGeom<LOGL>;
@@ -137,10 +140,31 @@ __device__ __forceinline__ void ntt_lds_stages(gl_t* lds, const gl_t* __restrict
                 tcol[q] = task & (G::T - 1);
                 tj[q] = task >> G::LOGT;
             }
+            constexpr int RIN = (ZP && LOGNS == 0) ? R / 8 : R;
 #pragma unroll
-            for (int r = 0; r < R; r++) u[q][r] = lds[G::at(tcol[q], tj[q] + (r << LOGJ))];
+            for (int r = 0; r < RIN; r++) u[q][r] = lds[G::at(tcol[q], tj[q] + (r << LOGJ))];
         }
         if constexpr (G::WAVE_OWNED) ntt_wave_sync(); else __syncthreads();
+        if constexpr (ZP && LOGNS == 0) {
+            static_assert(!ZP || LOGR >= 3, "zero-padded first stage needs radix >= 8");
+#pragma unroll
+            for (int q = 0; q < TPT; q++) {
+                const int j0 = tj[q] << LOGR;
+#pragma unroll
+                for (int o = 0; o < R; o++) {
+                    gl_t v = u[q][0];
+                    if constexpr (R == 16) {
+                        if (o) {            // w_16^o = 2^(156 o) (the reference's w_64 = 2^39); 2^96 = -1
+                            unsigned e = (156u * (unsigned)o) % 192u;
+                            if (INV) e = (192u - e) % 192u;
+                            const gl_t tt = gl_mul_2exp(u[q][1], e % 96u);
+                            v = (e >= 96u) ? gl_sub(v, tt) : gl_add(v, tt);
+                        } else v = gl_add(v, u[q][1]);
+                    }
+                    lds[G::at(tcol[q], j0 + o)] = v;
+                }
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < TPT; q++) {
             const int j = tj[q];
@@ -156,12 +180,12 @@ __device__ __forceinline__ void ntt_lds_stages(gl_t* lds, const gl_t* __restrict
             for (int o = 0; o < R; o++) lds[G::at(tcol[q], j0 + (o << LOGNS))] = u[q][ntt_bitrev(o, LOGR)];
         }
         if constexpr (G::WAVE_OWNED) ntt_wave_sync(); else __syncthreads();
-        ntt_lds_stages<LOGL, LOGNS + LOGR, INV>(lds, tw_local, tid);
+        ntt_lds_stages<LOGL, LOGNS + LOGR, INV, ZP>(lds, tw_local, tid);
     }
 }
 
 // COLUMN pass (pass A).  grid = (N2 / T, batch).
-template <int LOGL, bool INV>
+template <int LOGL, bool INV, bool ZP = false>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_col_pass(NttPassParams p) {
     using G = NttGeom<LOGL>;
     constexpr int LOGT = G::LOGT, T = G::T;
@@ -176,17 +200,18 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_col_pass(NttPassParams p) {
     const uint32_t lgN2 = p.lgN2;
     const gl_t* src = p.src + (uint64_t)b * p.src_stride;
     gl_t* dst = p.dst + (uint64_t)b * p.dst_stride;
-    // load: e -> (i1 = e / T, t = e % T), zero beyond n_in
-    gl_t v[NTT_EPT];
+    // load: e -> (i1 = e / T, t = e % T), zero beyond n_in; with ZP rows >= L/8 are known zeros and never touched
+    constexpr int QLOAD = ZP ? NTT_EPT / 8 : NTT_EPT;
+    gl_t v[QLOAD];
 #pragma unroll
-    for (int q = 0; q < NTT_EPT; q++) {
+    for (int q = 0; q < QLOAD; q++) {
         const int e = tid + NTT_THREADS * q;
         const uint32_t t = e & (T - 1), i1 = e >> LOGT;
         const uint32_t i = (i1 << lgN2) + c0 + t;
         v[q] = NTT_DBG(p, 2) ? (gl_t)e : ((i < p.n_in) ? src[i] : (gl_t)0);
     }
 #pragma unroll
-    for (int q = 0; q < NTT_EPT; q++) {
+    for (int q = 0; q < QLOAD; q++) {
         const int e = tid + NTT_THREADS * q;
         const uint32_t t = e & (T - 1), i1 = e >> LOGT;
         const uint32_t i = (i1 << lgN2) + c0 + t;
@@ -195,7 +220,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_col_pass(NttPassParams p) {
         lds[G::at(t, i1)] = x;
     }
     __syncthreads();
-    if (!NTT_DBG(p, 1)) ntt_lds_stages<LOGL, 0, INV>(lds, p.tw_local, tid);
+    if (!NTT_DBG(p, 1)) ntt_lds_stages<LOGL, 0, INV, ZP>(lds, p.tw_local, tid);
     if constexpr (G::WAVE_OWNED) __syncthreads();
     // store with the inter-pass twiddle w_N^(i2*k1)
 #pragma unroll 4

@@ -268,18 +268,27 @@ extern "C" int gl_copy_d2h(gl_ctx* c, void* h_dst, const void* d_src, size_t byt
 }
 
 // ---------------------------------------------------------------------------------------- launchers
-template <int LOGL, bool INV>
-static int launch_col(gl_ctx* c, const NttPassParams& p, dim3 grid) {
+template <int LOGL, bool INV, bool ZP>
+static int launch_col_impl(gl_ctx* c, const NttPassParams& p, dim3 grid) {
     constexpr size_t lds = NttGeom<LOGL>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        GL_CHECK_HIP(hipFuncSetAttribute((const void*)ntt_col_pass<LOGL, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GL_CHECK_HIP(hipFuncSetAttribute((const void*)ntt_col_pass<LOGL, INV, ZP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     GlTimed timed(c, INV ? "ntt_col_pass(inverse)" : "ntt_col_pass(forward)");
-    hipLaunchKernelGGL((ntt_col_pass<LOGL, INV>), grid, dim3(NTT_THREADS), lds, c->stream, p);
+    hipLaunchKernelGGL((ntt_col_pass<LOGL, INV, ZP>), grid, dim3(NTT_THREADS), lds, c->stream, p);
     GL_CHECK_HIP(hipGetLastError());
     return GL_OK;
+}
+template <int LOGL, bool INV>
+static int launch_col(gl_ctx* c, const NttPassParams& p, dim3 grid) {
+    // zero-padded input (LDE with rate >= 8, forward only): the first radix stage sees one or two non-zero inputs per task
+    if constexpr (!INV && LOGL >= 5 && LOGL <= 10) {
+        const uint64_t N = uint64_t(1) << (p.lgN1 + p.lgN2);
+        if ((uint64_t)p.n_in * 8 <= N) return launch_col_impl<LOGL, INV, true>(c, p, grid);
+    }
+    return launch_col_impl<LOGL, INV, false>(c, p, grid);
 }
 template <int LOGL, bool INV>
 static int launch_row(gl_ctx* c, const NttPassParams& p, dim3 grid) {
