@@ -17,6 +17,8 @@ struct gl_merkle {
     size_t num_leaves = 0, leaf_len = 0;
 };
 
+#define GL_COOP_MAX_NODES 8192u      // 8192 hashes x 16 lanes = 2048 waves = 2 per SIMD
+
 __device__ __forceinline__ uint32_t d_bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
 // digest of natural row r -> digests[bitrev(r)]
@@ -55,6 +57,33 @@ __global__ __launch_bounds__(256) void k_merkle_level(const gl_t* __restrict__ c
     ulonglong2* out = reinterpret_cast<ulonglong2*>(parent + 4ull * i);
     out[0] = make_ulonglong2(gl_canon(s[0]), gl_canon(s[1]));
     out[1] = make_ulonglong2(gl_canon(s[2]), gl_canon(s[3]));
+}
+
+// the same two kernels with one state per 16 lanes (psd_coop_permute): for launches too small to fill the chip
+__global__ __launch_bounds__(256) void k_merkle_level_coop(const gl_t* __restrict__ child, gl_t* __restrict__ parent, uint32_t count) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, node = gid >> 4;
+    const int l = (int)(gid & 15);
+    if (node >= count) return;                                    // whole 16-lane groups leave together
+    gl_t s = l < 8 ? child[8ull * node + l] : 0;
+    s = psd_coop_permute(s, l);
+    if (l < 4) parent[4ull * node + l] = gl_canon(s);
+}
+__global__ __launch_bounds__(256) void k_merkle_leaves_coop(const gl_t* __restrict__ base, const uint64_t* __restrict__ offsets,
+                                                            uint32_t leaf_len, uint32_t lg_leaves, gl_t* __restrict__ digests) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, r = gid >> 4;
+    const int l = (int)(gid & 15);
+    if (r >= (1u << lg_leaves)) return;
+    gl_t s = 0;
+    if (leaf_len <= 4) {   // hash_or_noop short path
+        if ((uint32_t)l < leaf_len) s = gl_canon(base[offsets[l] + r]);
+    } else {
+        for (uint32_t e0 = 0; e0 < leaf_len; e0 += 8) {
+            const uint32_t c = leaf_len - e0 < 8 ? leaf_len - e0 : 8;
+            if ((uint32_t)l < c) s = base[offsets[e0 + l] + r];
+            s = psd_coop_permute(s, l);
+        }
+    }
+    if (l < 4) digests[4ull * d_bitrev(r, lg_leaves) + l] = gl_canon(s);
 }
 
 __global__ void k_poseidon_states(gl_t* states, size_t count) {
@@ -108,13 +137,16 @@ int gl_merkle_build(gl_ctx* c, const gl_t* base, const uint64_t* host_offsets, u
     GL_TRY(c->get_offsets_table(host_offsets, leaf_len, &d_off));
     const uint32_t n = 1u << lg_leaves;
     c->timing_begin("merkle_leaf_hash");
-    hipLaunchKernelGGL(k_merkle_leaves, dim3((n + 255) / 256), dim3(256), 0, c->stream, base, d_off, leaf_len, lg_leaves, out->level_ptr(0));
+    // below GL_COOP_MAX_NODES one-lane-per-hash launches cannot fill the 1024 SIMDs: use 16 lanes per hash (latency / 3)
+    if (n <= GL_COOP_MAX_NODES) hipLaunchKernelGGL(k_merkle_leaves_coop, dim3((n * 16 + 255) / 256), dim3(256), 0, c->stream, base, d_off, leaf_len, lg_leaves, out->level_ptr(0));
+    else hipLaunchKernelGGL(k_merkle_leaves, dim3((n + 255) / 256), dim3(256), 0, c->stream, base, d_off, leaf_len, lg_leaves, out->level_ptr(0));
     c->timing_end();
     GL_CHECK_HIP(hipGetLastError());
     c->timing_begin("merkle_levels");
     for (uint32_t l = 1; l < levels; l++) {
         const uint32_t cnt = 1u << (lg_leaves - l);
-        hipLaunchKernelGGL(k_merkle_level, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, out->level_ptr(l - 1), out->level_ptr(l), cnt);
+        if (cnt <= GL_COOP_MAX_NODES) hipLaunchKernelGGL(k_merkle_level_coop, dim3((cnt * 16 + 255) / 256), dim3(256), 0, c->stream, out->level_ptr(l - 1), out->level_ptr(l), cnt);
+        else hipLaunchKernelGGL(k_merkle_level, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, out->level_ptr(l - 1), out->level_ptr(l), cnt);
     }
     c->timing_end();
     GL_CHECK_HIP(hipGetLastError());

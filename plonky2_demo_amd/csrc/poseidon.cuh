@@ -158,6 +158,45 @@ GL_HD void psd_permute(gl_t (&s)[12]) {         // host formulation (GL_HD only 
 }
 #endif
 
+#if defined(__HIPCC__)
+// Cooperative permutation for LATENCY-bound launches (the upper levels of a Merkle tree, the small FRI trees): 16 lanes
+// share one state, lane l < 12 holds word l, so the 12 S-boxes of a full round run side by side and the MDS layer is 22
+// cross-lane reads (ds_bpermute) plus 24 multiply-adds per lane.  The dependent chain of a permutation shrinks from
+// ~23 k to ~5 k instructions; three quarters of the lanes' issue slots are idle, so it only pays when the launch could
+// not fill the chip anyway.  `l` = lane & 15; lanes 12..15 carry zeros and mirror word 0's control flow.
+__device__ __forceinline__ gl_t psd_coop_permute(gl_t s, const int l) {
+    const uint32_t circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const gl_t* __restrict__ rc = d_POSEIDON_RC;
+    const int lc = l < 12 ? l : 0;
+    const int lane = (int)(threadIdx.x & 63), row = lane & ~15;
+    s = gl_add_c(s, rc[lc]);
+#pragma unroll 1
+    for (int r = 0; r < 8 + POSEIDON_PARTIAL_ROUNDS; r++) {
+        const bool full = r < 4 || r >= 4 + POSEIDON_PARTIAL_ROUNDS;
+        if (full || l == 0) s = psd_sbox(s);
+        const uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
+        gl_t al = 0, ah = 0;
+        if (r + 1 < 8 + POSEIDON_PARTIAL_ROUNDS) { const gl_t c = rc[12 * (r + 1) + lc]; al = (uint32_t)c; ah = c >> 32; }
+        al += (gl_t)lo * circ[0]; ah += (gl_t)hi * circ[0];
+#pragma unroll
+        for (int i = 1; i < 12; i++) {
+            int src = lc + i; src -= (src >= 12) ? 12 : 0;
+            const int addr = (row + src) << 2;
+            const uint32_t lo_i = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)lo);
+            const uint32_t hi_i = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)hi);
+            al += (gl_t)lo_i * circ[i]; ah += (gl_t)hi_i * circ[i];
+        }
+        if (l == 0) { al += (gl_t)lo * 8; ah += (gl_t)hi * 8; }   // MDS_MATRIX_DIAG[0] = 8
+        const uint32_t al_hi = (uint32_t)(al >> 32), ah_lo = (uint32_t)ah;
+        const uint32_t mid = al_hi + ah_lo;
+        const uint32_t top = (uint32_t)(ah >> 32) + (mid < ah_lo ? 1u : 0u);
+        s = gl_reduce96(((gl_t)mid << 32) | (uint32_t)al, top);
+        if (l >= 12) s = 0;
+    }
+    return s;
+}
+#endif
+
 // two_to_one (hashing.rs:98-115): permute([l, r, 0,0,0,0])[0..4]
 GL_HD void psd_two_to_one(const gl_t* l, const gl_t* r, gl_t* out) {
     gl_t s[12];
