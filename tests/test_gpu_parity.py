@@ -455,3 +455,37 @@ def test_demo_binary_builds_proves_and_verifies(gpu):
         assert r.returncode == 0, r.stderr
         assert r.stdout.strip() == "length of proof.public_inputs is %d" % (3 * m * m)      # matrix_mul.rs:90
         assert "accepted" in r.stderr
+
+
+def test_concurrent_proofs_on_shared_circuit_are_deterministic(gpu):
+    # four contexts (streams) of one device prove against ONE device-resident circuit from four host threads, as bench.py
+    # does: every proof must equal the single-stream proof of the same witness byte for byte (no cross-stream state)
+    import ctypes, threading
+    p, ctx = gpu
+    m = 20
+    hc = p.MatmulCircuit(m)
+    cd = hc.build(ctx)
+    wits = []
+    for k in range(3):
+        a, b = rand_field(300 + k, m * m) % (2**32 - 1), rand_field(400 + k, m * m) % (2**32 - 1)
+        wires, pis = hc.witness(a, b, filler_seed=k)
+        wits.append((ctx.alloc(wires.nbytes).upload(wires), pis, cd.prove(wires, pis).to_bytes()))
+    lanes = [(ctx, cd)] + [(lambda c: (c, p.api.CircuitView(cd, c)))(p.Context(device=0)) for _ in range(3)]
+    results, errors = {}, []
+
+    def work(lane):
+        try:
+            for rep in range(4):
+                for k, (buf, pis, _) in enumerate(wits):
+                    results[(lane, rep, k)] = lanes[lane][1].prove_device(buf.ptr, pis).to_bytes()
+            lanes[lane][0].synchronize()
+        except Exception as e:          # surfaced below: an assertion inside a thread would be lost
+            errors.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors
+    assert len(results) == 4 * 4 * 3
+    for (lane, rep, k), by in results.items():
+        assert by == wits[k][2], (lane, rep, k)
