@@ -144,6 +144,60 @@ def perm_fast(state, rc, T):
     return s
 
 
+GROUP = 3                                  # partial rounds evaluated per group on the GPU
+N_GROUPS = N_PARTIAL // GROUP              # 7 groups cover partial rounds 0..20; the 22nd runs alone
+
+
+def derive_groups(rc, M):
+    """GPU formulation of the partial rounds: three rounds at a time.
+
+    With T the state entering partial round r (round constants already added) and d_j = sbox(a_j) - a_j the change of
+    lane 0 in round r+j (a_j = lane 0 before its S-box), linearity of the rest of the round gives
+        a_1 = row0(M) T   + d_0 M[0][0]                    + k1
+        a_2 = row0(M^2) T + d_0 (M m0)[0] + d_1 M[0][0]     + k2
+        T'  = M^3 T + d_0 M^2 m0 + d_1 M m0 + d_2 m0        + K3          (m0 = column 0 of M)
+    where k1, k2, K3 collect the round constants of rounds r+1..r+3 pushed through M.  The entries of M^2 and M^3 are
+    below 2^15 and 2^25, so every product is still ONE 32 x 32 multiply-add per 32-bit half on the GPU."""
+    Mi = [[MDS_CIRC[(c - r) % W] + (MDS_DIAG[r] if r == c else 0) for c in range(W)] for r in range(W)]   # plain integers
+    imul = lambda A, B: [[sum(A[i][t] * B[t][j] for t in range(W)) for j in range(W)] for i in range(W)]
+    M2 = imul(Mi, Mi)
+    M3 = imul(M2, Mi)
+    assert max(max(r) for r in M2) < 2**15 and max(max(r) for r in M3) < 2**25
+    col0 = lambda A: [A[i][0] for i in range(W)]
+    G = dict(R1=Mi[0], R2=M2[0], M3=M3, V0=col0(Mi), V1=col0(M2), V2=col0(M3), K=[])
+    for g in range(N_GROUPS):
+        r = HALF_FULL + GROUP * g
+        C1, C2, C3 = rc[r + 1], rc[r + 2], rc[r + 3]
+        MC1 = mat_vec(M, C1)
+        k2v = [(a + b) % P for a, b in zip(MC1, C2)]
+        K3 = [(a + b) % P for a, b in zip(mat_vec(M, k2v), C3)]
+        G["K"].append([C1[0], k2v[0]] + K3)
+    return G
+
+
+def perm_grouped(state, rc, M, G):
+    s = [x % P for x in state]
+    r = 0
+    s = [(a + c) % P for a, c in zip(s, rc[0])]
+    for _ in range(HALF_FULL):          # T_{r+1} = M sbox(T_r) + rc[r+1]
+        s = [(a + c) % P for a, c in zip(mat_vec(M, [sbox(a) for a in s]), rc[r + 1])]; r += 1
+    dot = lambda row, v: sum(a * b for a, b in zip(row, v)) % P
+    for g in range(N_GROUPS):
+        k1, k2, K3 = G["K"][g][0], G["K"][g][1], G["K"][g][2:]
+        a0 = s[0]; d0 = (sbox(a0) - a0) % P
+        a1 = (dot(G["R1"], s) + d0 * G["V0"][0] + k1) % P; d1 = (sbox(a1) - a1) % P
+        a2 = (dot(G["R2"], s) + d0 * G["V1"][0] + d1 * G["V0"][0] + k2) % P; d2 = (sbox(a2) - a2) % P
+        s = [(dot(G["M3"][l], s) + d0 * G["V2"][l] + d1 * G["V1"][l] + d2 * G["V0"][l] + K3[l]) % P for l in range(W)]
+        r += GROUP
+    while r < HALF_FULL + N_PARTIAL:    # leftover partial round(s), textbook form
+        s[0] = sbox(s[0])
+        s = [(a + c) % P for a, c in zip(mat_vec(M, s), rc[r + 1])]; r += 1
+    for _ in range(HALF_FULL):
+        nxt = rc[r + 1] if r + 1 < N_ROUNDS else [0] * W
+        s = [(a + c) % P for a, c in zip(mat_vec(M, [sbox(a) for a in s]), nxt)]; r += 1
+    return s
+
+
 # Known-answer vectors: plonky2/src/hash/poseidon_goldilocks.rs:449-485 (data).
 KATS = [
     ([0] * 12,
@@ -167,12 +221,19 @@ KATS = [
 ]
 
 
-def emit(path, rc, T):
+def emit(path, rc, T, G):
     """Writes <path> (host wrapper, guarded) and <path minus .h>.inc (raw tables behind POSEIDON_TABLE)."""
     def arr(name, vals, per_line=4):
         out = ["POSEIDON_TABLE(%s, %d) = {" % (name, len(vals))]
         for i in range(0, len(vals), per_line):
             out.append("    " + ", ".join("0x%016xULL" % v for v in vals[i:i + per_line]) + ",")
+        out.append("};")
+        return "\n".join(out)
+
+    def arr32(name, vals, per_line=12):
+        out = ["POSEIDON_TABLE32(%s, %d) = {" % (name, len(vals))]
+        for i in range(0, len(vals), per_line):
+            out.append("    " + ", ".join("%du" % v for v in vals[i:i + per_line]) + ",")
         out.append("};")
         return "\n".join(out)
 
@@ -196,6 +257,13 @@ def emit(path, rc, T):
         arr("POSEIDON_PARTIAL_ROW", flat(T["rows_v"])),
         "// per partial round: out[i] = s[i] + s0*COL[r][i-1]",
         arr("POSEIDON_PARTIAL_COL", flat(T["cols_w"])),
+        "// GPU form of the partial rounds, three at a time (derive_groups): row 0 of M^2, M^3 row-major, column 0 of M^2 and",
+        "// of M^3 (plain integers < 2^25), and per group k1, k2, K3[12] (the round constants pushed through M)",
+        arr32("POSEIDON_G3_R2", G["R2"]),
+        arr32("POSEIDON_G3_M3", flat(G["M3"])),
+        arr32("POSEIDON_G3_V1", G["V1"]),
+        arr32("POSEIDON_G3_V2", G["V2"]),
+        arr("POSEIDON_G3_K", flat(G["K"])),
         "",
     ]
     inc_path = path[:-2] + ".inc" if path.endswith(".h") else path + ".inc"
@@ -209,9 +277,12 @@ def emit(path, rc, T):
         "#define POSEIDON_RATE 8",
         "#define POSEIDON_HALF_FULL_ROUNDS 4",
         "#define POSEIDON_PARTIAL_ROUNDS 22",
+        "#define POSEIDON_PARTIAL_GROUPS %d" % N_GROUPS,
         "#define POSEIDON_TABLE(name, n) static const uint64_t name[n]",
+        "#define POSEIDON_TABLE32(name, n) static const uint32_t name[n]",
         '#include "%s"' % os.path.basename(inc_path),
         "#undef POSEIDON_TABLE",
+        "#undef POSEIDON_TABLE32",
         "",
     ]
     with open(path, "w") as f:
@@ -224,14 +295,16 @@ def main():
     import random
     rnd = random.Random(1)
     tests = [k[0] for k in KATS] + [[rnd.randrange(P) for _ in range(W)] for _ in range(4)]
+    G = derive_groups(rc, T["M"])
     for t in tests:
         assert perm_naive(t, rc, T["M"]) == perm_fast(t, rc, T), "fast != naive"
+        assert perm_naive(t, rc, T["M"]) == perm_grouped(t, rc, T["M"], G), "grouped != naive"
     for inp, out in KATS:
         assert perm_fast(inp, rc, T) == out, "KAT mismatch"
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(
         HERE, "..", "plonky2_demo_amd", "csrc", "poseidon_constants.h")
-    emit(out, rc, T)
-    print("ok: naive==fast on %d inputs, 4 KATs pass; wrote %s" % (len(tests), os.path.normpath(out)))
+    emit(out, rc, T, G)
+    print("ok: naive==fast==grouped on %d inputs, 4 KATs pass; wrote %s" % (len(tests), os.path.normpath(out)))
     return T
 
 
