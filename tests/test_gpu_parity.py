@@ -489,3 +489,32 @@ def test_concurrent_proofs_on_shared_circuit_are_deterministic(gpu):
     assert len(results) == 4 * 4 * 3
     for (lane, rep, k), by in results.items():
         assert by == wits[k][2], (lane, rep, k)
+
+
+def test_phase_api_rejects_mismatched_arguments(gpu):
+    # the reference asserts on shape errors (oracle.rs:114,169); the phase entry points return GL_ERR_ARG instead
+    p, ctx = gpu
+    hc8, hc20 = p.MatmulCircuit(8), p.MatmulCircuit(20)
+    cd8, cd20 = hc8.build(), hc20.build()
+    a, b = rand_field(1, 64) % (2**32 - 1), rand_field(2, 64) % (2**32 - 1)
+    wires, pis = hc8.witness(a, b)
+    d_w = ctx.alloc(wires.nbytes).upload(wires)
+    wb = p.PolynomialBatch.from_device(d_w.ptr, 135, hc8.n, 3, 4, True)
+    zs = cd8.partial_products(d_w.ptr, [3, 5], [7, 11])
+    assert zs.ncols == 20 and zs.degree == hc8.n
+    with pytest.raises(p.Plonky2Mi355xError):
+        cd20.quotient_polys(wb, zs, [1, 2, 3, 4], [3, 5], [7, 11], [13, 17])       # batches of another circuit size
+    with pytest.raises(p.Plonky2Mi355xError):
+        cd8.quotient_polys(zs, wb, [1, 2, 3, 4], [3, 5], [7, 11], [13, 17])        # wires / Z batches swapped
+    q = cd8.quotient_polys(wb, zs, [1, 2, 3, 4], [3, 5], [7, 11], [13, 17])
+    with pytest.raises(p.Plonky2Mi355xError):
+        cd8.fri([wb, cd8.constants_sigmas_batch, zs, q], [2, 3], [5, 7])            # wrong oracle order
+    with pytest.raises(p.Plonky2Mi355xError):
+        wb.open_at([1, 2], first_col=130, num_cols=10)                              # column range out of bounds
+    with pytest.raises(p.Plonky2Mi355xError):
+        p.pow_grind(np.zeros(12, dtype=np.uint64), np.zeros(8, dtype=np.uint64), 16)   # no room for the witness in the rate
+    fri = cd8.fri([cd8.constants_sigmas_batch, wb, zs, q], [2, 3], [5, 7])
+    with pytest.raises(p.Plonky2Mi355xError):
+        fri.final_poly()                                                              # reduction rounds not finished
+    with pytest.raises(p.Plonky2Mi355xError):
+        fri.query([0])
