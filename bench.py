@@ -109,13 +109,13 @@ def ntt_leg(torch, ctx, lib, check, dev, batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=80)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--m", type=int, default=M)
     ap.add_argument("--witnesses", type=int, default=4, help="distinct random witnesses cycled through")
     ap.add_argument("--ntt-batch", type=int, default=64)
     ap.add_argument("--streams", type=int, default=4, help="independent proofs in flight per GPU (one HIP stream + host thread each)")
-    ap.add_argument("--e2e-steps", type=int, default=32, help="proofs of the secondary run that also times witness generation (0 = skip)")
+    ap.add_argument("--e2e-steps", type=int, default=48, help="proofs of the secondary run that also times witness generation (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
