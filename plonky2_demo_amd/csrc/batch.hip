@@ -33,6 +33,7 @@ static int batch_commit(gl_ctx* c, gl_batch* b, const gl_t* values) {
     return GL_OK;
 }
 
+extern "C" void gl_batch_free(gl_batch* b);
 static int batch_alloc(gl_ctx* c, size_t ncols, size_t n, uint32_t rate_bits, uint32_t cap_height, gl_batch** out) {
     GL_REQUIRE(c && out && ncols >= 1 && n >= 1, GL_ERR_ARG, "PolynomialBatch: bad argument");
     uint32_t lg = 0;
@@ -43,8 +44,9 @@ static int batch_alloc(gl_ctx* c, size_t ncols, size_t n, uint32_t rate_bits, ui
     GL_TRY(c->activate());
     gl_batch* b = new gl_batch();
     b->ctx = c; b->ncols = ncols; b->n = n; b->degree_log = lg; b->rate_bits = rate_bits; b->cap_height = cap_height;
-    GL_TRY(c->pool_alloc(ncols * n * sizeof(gl_t), (void**)&b->coeffs));
-    GL_TRY(c->pool_alloc(ncols * b->N() * sizeof(gl_t), (void**)&b->lde));
+    int st = c->pool_alloc(ncols * n * sizeof(gl_t), (void**)&b->coeffs);
+    if (st == GL_OK) st = c->pool_alloc(ncols * b->N() * sizeof(gl_t), (void**)&b->lde);
+    if (st != GL_OK) { gl_batch_free(b); return st; }      // nothing leaks when the device is out of memory
     *out = b;
     return GL_OK;
 }
@@ -143,7 +145,7 @@ extern "C" const uint64_t* gl_batch_dev_lde(const gl_batch* b) { return b ? b->l
 extern "C" void gl_batch_free(gl_batch* b) {
     if (!b) return;
     gl_merkle_release(b->ctx, &b->tree);
-    b->ctx->pool_release(b->coeffs);
-    b->ctx->pool_release(b->lde);
+    if (b->coeffs) b->ctx->pool_release(b->coeffs);
+    if (b->lde) b->ctx->pool_release(b->lde);
     delete b;
 }

@@ -205,3 +205,21 @@ def test_prover_with_fri_rounds_and_tampering(orc):
         bad.tamper(what)
         ok, msg = bad.verify()
         assert not ok and needle in msg, (what, msg)
+
+
+def test_proof_regression_hashes(orc):
+    # Proofs are deterministic functions of (circuit, witness matrix): these SHA-256 values were recorded from the oracle
+    # when it was first validated (verifier accepts, GPU byte-identical) and pin BOTH implementations against silent drift,
+    # e.g. a change of the PoW choice or of the serialisation order that would still verify.
+    import hashlib, json, os
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "proof_hashes.json")))
+    c = orc.circuit(2)
+    assert hashlib.sha256(c.witness([1, 2, 3, 4], [5, 6, 7, 8]).prove().to_bytes()).hexdigest() == want["readme_m2"]
+    for m, seed in ((1, 11), (3, 12), (8, 13), (20, 14)):
+        oc = orc.circuit(m, threads=8)
+        a, b = rand_field(seed, m * m) % (2**32 - 1), rand_field(seed + 100, m * m) % (2**32 - 1)
+        pr = oc.witness(a, b, filler_seed=seed).prove(threads=8)
+        w = want["m%d_seed%d" % (m, seed)]
+        assert [int(x) for x in oc.digest] == w["digest"]
+        assert len(pr.to_bytes()) == w["bytes"] and pr.challenges()["pow_witness"] == w["pow_witness"]
+        assert hashlib.sha256(pr.to_bytes()).hexdigest() == w["sha256"]
