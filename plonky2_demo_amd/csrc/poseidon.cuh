@@ -150,6 +150,63 @@ GL_HD void psd_sbox_all(gl_t (&s)[12]) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = psd_sbox(s[i]);
 }
+#if defined(__HIPCC__)
+// Three partial rounds at once (tools/gen_poseidon_constants.py derive_groups): with d_j = sbox(x_j) - a_j the change of lane
+// 0 in round j of the group (a_j = lane 0 entering its S-box), everything else is linear, so lane 0 of the next two rounds
+// needs only row 0 of M and of M^2 applied to the group's input state, and the state after the group is M^3 (entries
+// < 2^25: still one multiply-add per 32-bit half) applied to it plus three rank-one corrections: ~910 instead of 3 x 500
+// instructions.  `s` enters and leaves with the round constants of its next round already added.
+// SUBST = false: x_j = a_j (the permutation).  SUBST = true: x_j = in[j], the PoseidonGate's S-box input wires, and a[j]
+// returns the computed a_j for the constraint a_j - in[j] (gates/poseidon.rs:165-189).
+template <bool SUBST>
+__device__ __forceinline__ void psd_partial_group(gl_t (&s)[12], int g, const gl_t* in, gl_t* a) {
+    const gl_t* __restrict__ K = d_POSEIDON_G3_K + 14 * g;
+    // the matrix constants are re-read (scalar loads) in every group: hoisted out of the loop they exceed the SGPR file
+    // and get parked in VGPR lanes (250 v_readlane per group)
+    uint32_t z = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(z));
+#endif
+    const uint32_t* __restrict__ R2 = d_POSEIDON_G3_R2 + z;
+    const uint32_t* __restrict__ M3 = d_POSEIDON_G3_M3 + z;
+    const uint32_t* __restrict__ V1 = d_POSEIDON_G3_V1 + z;
+    const uint32_t* __restrict__ V2 = d_POSEIDON_G3_V2 + z;
+    uint32_t lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { lo[i] = (uint32_t)s[i]; hi[i] = (uint32_t)(s[i] >> 32); }
+    a[0] = s[0];
+    const gl_t d0 = gl_sub(psd_sbox(SUBST ? in[0] : s[0]), s[0]);
+    const uint32_t d0l = (uint32_t)d0, d0h = (uint32_t)(d0 >> 32);
+    gl_t al = (uint32_t)K[0], ah = K[0] >> 32;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { const uint32_t c = psd_mds_entry(0, i); al += (gl_t)lo[i] * c; ah += (gl_t)hi[i] * c; }
+    al += (gl_t)d0l * 25u; ah += (gl_t)d0h * 25u;                      // M[0][0]
+    const gl_t a1 = psd_acc_reduce(al, ah);
+    a[1] = a1;
+    const gl_t d1 = gl_sub(psd_sbox(SUBST ? in[1] : a1), a1);
+    const uint32_t d1l = (uint32_t)d1, d1h = (uint32_t)(d1 >> 32);
+    al = (uint32_t)K[1]; ah = K[1] >> 32;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { const uint32_t c = R2[i]; al += (gl_t)lo[i] * c; ah += (gl_t)hi[i] * c; }
+    { const uint32_t c = V1[0]; al += (gl_t)d0l * c; ah += (gl_t)d0h * c; }
+    al += (gl_t)d1l * 25u; ah += (gl_t)d1h * 25u;
+    const gl_t a2 = psd_acc_reduce(al, ah);
+    a[2] = a2;
+    const gl_t d2 = gl_sub(psd_sbox(SUBST ? in[2] : a2), a2);
+    const uint32_t d2l = (uint32_t)d2, d2h = (uint32_t)(d2 >> 32);
+#pragma unroll
+    for (int l = 0; l < 12; l++) {
+        al = (uint32_t)K[2 + l]; ah = K[2 + l] >> 32;
+#pragma unroll
+        for (int i = 0; i < 12; i++) { const uint32_t c = M3[12 * l + i]; al += (gl_t)lo[i] * c; ah += (gl_t)hi[i] * c; }
+        { const uint32_t c = V2[l]; al += (gl_t)d0l * c; ah += (gl_t)d0h * c; }
+        { const uint32_t c = V1[l]; al += (gl_t)d1l * c; ah += (gl_t)d1h * c; }
+        { const uint32_t c = psd_mds_entry(l, 0); al += (gl_t)d2l * c; ah += (gl_t)d2h * c; }
+        s[l] = psd_acc_reduce(al, ah);
+    }
+}
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 GL_HD void psd_permute(gl_t (&s)[12]) {       // (host + device only so that host code parses in the device pass)
     const gl_t* __restrict__ rc = d_POSEIDON_RC;
@@ -157,52 +214,8 @@ GL_HD void psd_permute(gl_t (&s)[12]) {       // (host + device only so that hos
     for (int i = 0; i < 12; i++) s[i] = gl_add_c(s[i], rc[i]);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) { psd_sbox_all(s); psd_mds_then_constants<true>(s, rc + 12 * (r + 1)); }
-    // partial rounds three at a time (tools/gen_poseidon_constants.py derive_groups): with d_j = sbox(a_j) - a_j the change of
-    // lane 0 in round j of the group, everything else is linear, so lane 0 of the next two rounds needs only row 0 of M and
-    // of M^2 applied to the group's input state, and the state after the group is M^3 (entries < 2^25: still one multiply-
-    // add per 32-bit half) applied to it plus three rank-one corrections: ~860 instead of 3 x 500 instructions
 #pragma unroll 1
-    for (int g = 0; g < POSEIDON_PARTIAL_GROUPS; g++) {
-        const gl_t* __restrict__ K = d_POSEIDON_G3_K + 14 * g;
-        // the matrix constants are re-read (scalar loads) in every group: hoisted out of the loop they exceed the SGPR file
-        // and get parked in VGPR lanes (250 v_readlane per group)
-        uint32_t z = 0;
-        asm volatile("" : "+s"(z));
-        const uint32_t* __restrict__ R2 = d_POSEIDON_G3_R2 + z;
-        const uint32_t* __restrict__ M3 = d_POSEIDON_G3_M3 + z;
-        const uint32_t* __restrict__ V1 = d_POSEIDON_G3_V1 + z;
-        const uint32_t* __restrict__ V2 = d_POSEIDON_G3_V2 + z;
-        uint32_t lo[12], hi[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) { lo[i] = (uint32_t)s[i]; hi[i] = (uint32_t)(s[i] >> 32); }
-        const gl_t d0 = gl_sub(psd_sbox(s[0]), s[0]);
-        const uint32_t d0l = (uint32_t)d0, d0h = (uint32_t)(d0 >> 32);
-        gl_t al = (uint32_t)K[0], ah = K[0] >> 32;
-#pragma unroll
-        for (int i = 0; i < 12; i++) { const uint32_t c = psd_mds_entry(0, i); al += (gl_t)lo[i] * c; ah += (gl_t)hi[i] * c; }
-        al += (gl_t)d0l * 25u; ah += (gl_t)d0h * 25u;                      // M[0][0]
-        const gl_t a1 = psd_acc_reduce(al, ah);
-        const gl_t d1 = gl_sub(psd_sbox(a1), a1);
-        const uint32_t d1l = (uint32_t)d1, d1h = (uint32_t)(d1 >> 32);
-        al = (uint32_t)K[1]; ah = K[1] >> 32;
-#pragma unroll
-        for (int i = 0; i < 12; i++) { const uint32_t c = R2[i]; al += (gl_t)lo[i] * c; ah += (gl_t)hi[i] * c; }
-        { const uint32_t c = V1[0]; al += (gl_t)d0l * c; ah += (gl_t)d0h * c; }
-        al += (gl_t)d1l * 25u; ah += (gl_t)d1h * 25u;
-        const gl_t a2 = psd_acc_reduce(al, ah);
-        const gl_t d2 = gl_sub(psd_sbox(a2), a2);
-        const uint32_t d2l = (uint32_t)d2, d2h = (uint32_t)(d2 >> 32);
-#pragma unroll
-        for (int l = 0; l < 12; l++) {
-            al = (uint32_t)K[2 + l]; ah = K[2 + l] >> 32;
-#pragma unroll
-            for (int i = 0; i < 12; i++) { const uint32_t c = M3[12 * l + i]; al += (gl_t)lo[i] * c; ah += (gl_t)hi[i] * c; }
-            { const uint32_t c = V2[l]; al += (gl_t)d0l * c; ah += (gl_t)d0h * c; }
-            { const uint32_t c = V1[l]; al += (gl_t)d1l * c; ah += (gl_t)d1h * c; }
-            { const uint32_t c = psd_mds_entry(l, 0); al += (gl_t)d2l * c; ah += (gl_t)d2h * c; }
-            s[l] = psd_acc_reduce(al, ah);
-        }
-    }
+    for (int g = 0; g < POSEIDON_PARTIAL_GROUPS; g++) { gl_t a[3]; psd_partial_group<false>(s, g, nullptr, a); }
 #pragma unroll 1
     for (int r = 4 + 3 * POSEIDON_PARTIAL_GROUPS; r < 4 + POSEIDON_PARTIAL_ROUNDS; r++) { s[0] = psd_sbox(s[0]); psd_mds_then_constants<true>(s, rc + 12 * (r + 1)); }
 #pragma unroll 1

@@ -212,7 +212,16 @@ __device__ __forceinline__ void glq_poseidon_gate(const gl_t* __restrict__ w, si
         psd_mds_then_constants<true>(s, rc + 12 * (r + 1));
     }
 #pragma unroll 1
-    for (int r = 0; r < POSEIDON_PARTIAL_ROUNDS; r++) {  // 65..86
+    for (int g = 0; g < POSEIDON_PARTIAL_GROUPS; g++) {  // 65..85: three partial rounds at a time (psd_partial_group)
+        gl_t in[3], a[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { in[j] = *wp; wp = glq_step(wp, N); }
+        psd_partial_group<true>(s, g, in, a);
+#pragma unroll
+        for (int j = 0; j < 3; j++) acc.add(t++, gl_sub(a[j], in[j]));
+    }
+#pragma unroll 1
+    for (int r = 3 * POSEIDON_PARTIAL_GROUPS; r < POSEIDON_PARTIAL_ROUNDS; r++) {  // 86
         const gl_t in = *wp; wp = glq_step(wp, N);
         acc.add(t++, gl_sub(s[0], in));
         s[0] = psd_sbox(in);
