@@ -87,6 +87,15 @@ def test_coset_lde_matches_oracle(gpu, orc, lg, rate):
     assert (p.lde_onto_coset(x, rate) == orc.lde(x, rate, threads=4)).all()
 
 
+@pytest.mark.parametrize("lg,rate,batch", [(17, 3, 2), (11, 3, 7), (14, 3, 5), (16, 4, 4), (12, 2, 6)])
+def test_coset_lde_batches_and_config2_shape(gpu, orc, lg, rate, batch):
+    # BASELINE config 2's LDE shape (2^17 -> 2^20, coset 7, benches/ffts.rs:21-37) and batches of >= 4 polynomials, which
+    # take the inter-pass twiddle table and (rate >= 8) the zero-padding-aware first stage of the column pass
+    p, ctx = gpu
+    x = rand_field(700 + lg, (batch, 1 << lg))
+    assert (p.lde_onto_coset(x, rate) == orc.lde(x, rate, threads=8)).all()
+
+
 def test_ntt_non_canonical_input(gpu, orc):
     p, ctx = gpu
     x = np.random.default_rng(7).integers(0, 2**64, size=(2, 1 << 13), dtype=np.uint64)
