@@ -99,7 +99,10 @@ def ntt_leg(torch, ctx, lib, check, dev, batch):
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel": "forward 2^20 NTT x %d polynomials = ntt_col_pass<10> + ntt_row_pass<10>" % batch,
-                "algorithmic_bytes": algo, "launches": launches}
+                "algorithmic_bytes": algo, "launches": launches,
+                "note": "VALU-issue-bound on gfx950 (no 64x64 multiplier): ~390 VALU instructions per element over the two passes at "
+                        "the measured ~0.55 wave-instructions/ns/SIMD cap this instruction stream near 18 % of the HBM roof "
+                        "(DESIGN.md section 4, profiles/README.md)"}
     ntt = {"metric": "Goldilocks NTT GF-elems/sec at 2^20 (forward+inverse)", "value": reps * 2.0 * batch * L / dt, "unit": "GF-elems/s",
            "batch": batch, "round_trip_bit_exact": intact}
     del data, ref
