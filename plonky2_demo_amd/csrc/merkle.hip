@@ -17,7 +17,12 @@ struct gl_merkle {
     size_t num_leaves = 0, leaf_len = 0;
 };
 
-#define GL_COOP_MAX_NODES 8192u      // 8192 hashes x 16 lanes = 2048 waves = 2 per SIMD
+#define GL_COOP_MAX_NODES_DEFAULT 8192u      // 8192 hashes x 16 lanes = 2048 waves = 2 per SIMD
+// tuning knob (environment GL_COOP_MAX_NODES): launches of at most this many hashes use the 16-lane cooperative permutation
+static uint32_t gl_coop_max_nodes() {
+    static const uint32_t v = [] { const char* e = getenv("GL_COOP_MAX_NODES"); return e ? (uint32_t)strtoul(e, nullptr, 10) : GL_COOP_MAX_NODES_DEFAULT; }();
+    return v;
+}
 
 __device__ __forceinline__ uint32_t d_bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
@@ -137,15 +142,15 @@ int gl_merkle_build(gl_ctx* c, const gl_t* base, const uint64_t* host_offsets, u
     GL_TRY(c->get_offsets_table(host_offsets, leaf_len, &d_off));
     const uint32_t n = 1u << lg_leaves;
     c->timing_begin("merkle_leaf_hash");
-    // below GL_COOP_MAX_NODES one-lane-per-hash launches cannot fill the 1024 SIMDs: use 16 lanes per hash (latency / 3)
-    if (n <= GL_COOP_MAX_NODES) hipLaunchKernelGGL(k_merkle_leaves_coop, dim3((n * 16 + 255) / 256), dim3(256), 0, c->stream, base, d_off, leaf_len, lg_leaves, out->level_ptr(0));
+    // below gl_coop_max_nodes() one-lane-per-hash launches cannot fill the 1024 SIMDs: use 16 lanes per hash (latency / 3)
+    if (n <= gl_coop_max_nodes()) hipLaunchKernelGGL(k_merkle_leaves_coop, dim3((n * 16 + 255) / 256), dim3(256), 0, c->stream, base, d_off, leaf_len, lg_leaves, out->level_ptr(0));
     else hipLaunchKernelGGL(k_merkle_leaves, dim3((n + 255) / 256), dim3(256), 0, c->stream, base, d_off, leaf_len, lg_leaves, out->level_ptr(0));
     c->timing_end();
     GL_CHECK_HIP(hipGetLastError());
     c->timing_begin("merkle_levels");
     for (uint32_t l = 1; l < levels; l++) {
         const uint32_t cnt = 1u << (lg_leaves - l);
-        if (cnt <= GL_COOP_MAX_NODES) hipLaunchKernelGGL(k_merkle_level_coop, dim3((cnt * 16 + 255) / 256), dim3(256), 0, c->stream, out->level_ptr(l - 1), out->level_ptr(l), cnt);
+        if (cnt <= gl_coop_max_nodes()) hipLaunchKernelGGL(k_merkle_level_coop, dim3((cnt * 16 + 255) / 256), dim3(256), 0, c->stream, out->level_ptr(l - 1), out->level_ptr(l), cnt);
         else hipLaunchKernelGGL(k_merkle_level, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, out->level_ptr(l - 1), out->level_ptr(l), cnt);
     }
     c->timing_end();
