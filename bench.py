@@ -49,7 +49,10 @@ def cpu_baseline(m):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     orc = oracle_lib.load()
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))       # the CPU share this process may actually run on
+    except AttributeError:
+        cores = os.cpu_count() or 1
     threads = min(cores, 64)
     oc = orc.circuit(m, threads=threads)
     a = oracle_lib.rand_field(64, m * m) % (2**32 - 1)
