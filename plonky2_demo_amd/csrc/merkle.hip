@@ -91,6 +91,28 @@ __global__ __launch_bounds__(256) void k_merkle_leaves_coop(const gl_t* __restri
     if (l < 4) digests[4ull * d_bitrev(r, lg_leaves) + l] = gl_canon(s);
 }
 
+// The top of the tree in ONE launch: the 2^cap_height subtrees under the cap are independent, so workgroup b walks subtree
+// b from the level with GL_TOP_NODES nodes per subtree up to its root (a cap entry) with workgroup barriers between levels,
+// 16 lanes per hash.  Replaces log2(GL_TOP_NODES) + 1 dependent launches (each ~14 us of work behind a ~8 us dispatch gap).
+// digests: level-ordered array, `lev_off[l]` = first digest of level l; first_level = level whose nodes are computed first.
+#define GL_TOP_NODES 64u                // 64 hashes x 16 lanes = one 1024-thread workgroup
+__global__ __launch_bounds__(1024) void k_merkle_top_coop(gl_t* __restrict__ digests, const uint64_t* __restrict__ lev_off, uint32_t first_level,
+                                                          uint32_t num_levels, uint32_t nodes_first /* per subtree at first_level */) {
+    const uint32_t sub = blockIdx.x, g = threadIdx.x >> 4;
+    const int l = (int)(threadIdx.x & 15);
+    uint32_t nodes = nodes_first;
+    for (uint32_t lev = first_level; lev < num_levels; lev++, nodes >>= 1) {
+        const gl_t* child = digests + 4 * lev_off[lev - 1] + 8ull * sub * nodes;      // 2 * nodes children of this subtree
+        gl_t* parent = digests + 4 * lev_off[lev] + 4ull * sub * nodes;
+        if (g < nodes) {
+            gl_t s = l < 8 ? child[8ull * g + l] : 0;
+            s = psd_coop_permute(s, l);
+            if (l < 4) parent[4ull * g + l] = gl_canon(s);
+        }
+        __syncthreads();                                                              // the next level reads what this one wrote
+    }
+}
+
 __global__ void k_poseidon_states(gl_t* states, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -148,11 +170,22 @@ int gl_merkle_build(gl_ctx* c, const gl_t* base, const uint64_t* host_offsets, u
     c->timing_end();
     GL_CHECK_HIP(hipGetLastError());
     c->timing_begin("merkle_levels");
-    for (uint32_t l = 1; l < levels; l++) {
+    // levels with at most GL_TOP_NODES nodes per cap subtree are finished by one launch (k_merkle_top_coop)
+    uint32_t top_first = levels;
+    if (gl_coop_max_nodes() > 0)
+        for (uint32_t l = 1; l < levels; l++)
+            if (((1u << (lg_leaves - l)) >> cap_height) <= GL_TOP_NODES && ((1u << (lg_leaves - l)) >> cap_height) >= 1) { top_first = l; break; }
+    const uint64_t* d_lev_off = nullptr;
+    if (top_first < levels && levels - top_first >= 2) GL_TRY(c->get_offsets_table(out->level_off.data(), out->level_off.size(), &d_lev_off));
+    else top_first = levels;
+    for (uint32_t l = 1; l < top_first; l++) {
         const uint32_t cnt = 1u << (lg_leaves - l);
         if (cnt <= gl_coop_max_nodes()) hipLaunchKernelGGL(k_merkle_level_coop, dim3((cnt * 16 + 255) / 256), dim3(256), 0, c->stream, out->level_ptr(l - 1), out->level_ptr(l), cnt);
         else hipLaunchKernelGGL(k_merkle_level, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, out->level_ptr(l - 1), out->level_ptr(l), cnt);
     }
+    if (top_first < levels)
+        hipLaunchKernelGGL(k_merkle_top_coop, dim3(1u << cap_height), dim3(1024), 0, c->stream, out->digests, d_lev_off, top_first, levels,
+                           (1u << (lg_leaves - top_first)) >> cap_height);
     c->timing_end();
     GL_CHECK_HIP(hipGetLastError());
     return GL_OK;
