@@ -10,6 +10,7 @@
 // Host (Challenger, public_inputs_hash, witness rows, verifier): the factorised "fast" partial rounds of
 // poseidon.rs:311-366,399-427 with 128-bit lazy dot products; its tables are derived by tools/gen_poseidon_constants.py.
 #pragma once
+#include <stdlib.h>
 #include "gl64.cuh"
 #include "poseidon_constants.h"
 
@@ -87,7 +88,7 @@ __attribute__((target("avx2"))) inline void psd_mds_avx2(gl_t (&s)[12]) {
     psd_mds_finish(s, AL, AH);
 }
 inline void psd_mds(gl_t (&s)[12]) {
-    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    static const bool have_avx2 = __builtin_cpu_supports("avx2") && !getenv("GL_HOST_MDS_PORTABLE");
     if (have_avx2) psd_mds_avx2(s); else psd_mds_portable(s);
 }
 #else
