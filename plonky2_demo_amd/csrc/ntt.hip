@@ -1,5 +1,6 @@
 // NTT launchers, context management and the NTT / field entry points of the C ABI.
 #include "context.hpp"
+#include <atomic>
 #include "ntt.cuh"
 #include <cstdio>
 #include <cstring>
@@ -271,10 +272,12 @@ extern "C" int gl_copy_d2h(gl_ctx* c, void* h_dst, const void* d_src, size_t byt
 template <int LOGL, bool INV, bool ZP>
 static int launch_col_impl(gl_ctx* c, const NttPassParams& p, dim3 grid) {
     constexpr size_t lds = NttGeom<LOGL>::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // once per instantiation and device; contexts on several host threads may get here together (setting it twice is harmless)
+    static std::atomic<uint64_t> done{0};
+    const uint64_t bit = uint64_t(1) << (c->device & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
         GL_CHECK_HIP(hipFuncSetAttribute((const void*)ntt_col_pass<LOGL, INV, ZP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        done.fetch_or(bit, std::memory_order_release);
     }
     GlTimed timed(c, INV ? "ntt_col_pass(inverse)" : "ntt_col_pass(forward)");
     hipLaunchKernelGGL((ntt_col_pass<LOGL, INV, ZP>), grid, dim3(NTT_THREADS), lds, c->stream, p);
@@ -293,10 +296,11 @@ static int launch_col(gl_ctx* c, const NttPassParams& p, dim3 grid) {
 template <int LOGL, bool INV>
 static int launch_row(gl_ctx* c, const NttPassParams& p, dim3 grid) {
     constexpr size_t lds = NttGeom<LOGL>::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> done{0};
+    const uint64_t bit = uint64_t(1) << (c->device & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
         GL_CHECK_HIP(hipFuncSetAttribute((const void*)ntt_row_pass<LOGL, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        done.fetch_or(bit, std::memory_order_release);
     }
     GlTimed timed(c, INV ? "ntt_row_pass(inverse)" : "ntt_row_pass(forward)");
     hipLaunchKernelGGL((ntt_row_pass<LOGL, INV>), grid, dim3(NTT_THREADS), lds, c->stream, p);
