@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--ntt-batch", type=int, default=64)
     ap.add_argument("--streams", type=int, default=4, help="independent proofs in flight per GPU (one HIP stream + host thread each)")
     ap.add_argument("--e2e-steps", type=int, default=48, help="proofs of the secondary run that also times witness generation (0 = skip)")
+    ap.add_argument("--e2e-lanes", type=int, default=0, help="proofs in flight of the secondary run (default: three times --streams)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -213,9 +214,9 @@ def main():
         # arithmetic rows filled by the GPU, the sequential public-input hash sponge by the lane's host thread
         e2e = None
         if args.e2e_steps > 0:
-            # the host part of witness generation (7 ms of sequential Poseidon per proof) is hidden by keeping twice as many
-            # proofs in flight: while one lane's host thread hashes, the GPU works on the other lanes' proofs
-            nl = 2 * nstreams
+            # the host part of witness generation (several ms of sequential Poseidon per proof) is hidden by keeping three times
+            # as many proofs in flight: while one lane's host thread hashes, the GPU works on the other lanes' proofs
+            nl = args.e2e_lanes if args.e2e_lanes > 0 else 3 * nstreams
             el = lanes + [(lambda c: (c, p.api.CircuitView(cd, c)))(p.Context(device=local_rank)) for _ in range(nl - nstreams)]
             gens = [hc.witness_generator(c) for c, _ in el]
             bufs = [torch.empty((135, hc.n), dtype=torch.int64, device=dev) for _ in el]
