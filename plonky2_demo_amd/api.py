@@ -96,15 +96,13 @@ class Context:
         return json.loads(buf.value.decode())
 
     def close(self):
+        """Destroys the context.  Every batch / tree / circuit / buffer created on it must have been freed before."""
         if self.handle:
             lib.gl_ctx_destroy(self.handle)
             self.handle = None
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+    # no __del__: handles created on a context keep raw pointers into it and Python gives no destruction order (least of
+    # all at interpreter shutdown), so a context lives until close() or process exit
 
 
 _default = None
