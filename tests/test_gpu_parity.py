@@ -190,6 +190,23 @@ def test_merkle_tree_golden_and_oracle(gpu, orc, golden):
     assert (p.MerkleTree(one, 0).cap == orc.merkle(one, 0).cap).all()
 
 
+@pytest.mark.parametrize("lg", [0, 1, 2, 3, 5, 7, 9, 10, 11, 12, 13, 14, 15])
+def test_merkle_shapes_across_kernel_paths(gpu, orc, lg):
+    # tree shapes on both sides of every kernel switch: one hash per lane / 16 lanes per hash (<= 8192 hashes), and the
+    # single-launch tree top (levels with <= 64 nodes per cap subtree), for cap heights 0..5 and short / long leaves
+    p, ctx = gpu
+    n = 1 << lg
+    for leaf_len in (1, 4, 5, 8, 32):
+        leaves = rand_field(5000 + 10 * lg + leaf_len, (n, leaf_len))
+        for cap_height in sorted({0, 1, 4, 5, lg} & set(range(lg + 1))):
+            tree = p.MerkleTree(leaves, cap_height)
+            ot = orc.merkle(leaves, cap_height)
+            assert (tree.cap == ot.cap).all(), (lg, leaf_len, cap_height)
+            for i in sorted({0, n // 3, n - 1}):
+                sib = tree.prove(i)
+                assert (sib == ot.prove(i)).all(), (lg, leaf_len, cap_height, i)
+
+
 # -------------------------------------------------------------------------------------- PolynomialBatch
 def test_polynomial_batch_golden(gpu, golden):
     p, ctx = gpu
