@@ -108,7 +108,32 @@ def ntt_leg(torch, ctx, lib, check, dev, batch):
                         "(DESIGN.md section 4, profiles/README.md)"}
     ntt = {"metric": "Goldilocks NTT GF-elems/sec at 2^20 (forward+inverse)", "value": reps * 2.0 * batch * L / dt, "unit": "GF-elems/s",
            "batch": batch, "round_trip_bit_exact": intact}
-    del data, ref
+    # the two reference points SURVEY 8(d) asks for next to the roofline fraction: a measured device copy (what "HBM-bound"
+    # can reach on this box) and the integer-ALU rate of the kernel family that actually bounds prove()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    dst = torch.empty_like(data)
+    dst.copy_(data)
+    ev[0].record()
+    for _ in range(5):
+        dst.copy_(data)
+    ev[1].record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2.0 * data.numel() * 8 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
+    nperm = 1 << 23                                     # ~4 ms of work: host-clock timing around a context sync is accurate enough
+    states = synth_field(torch, (nperm, 12), 21, dev)
+    torch.cuda.synchronize()
+    check(lib.gl_poseidon_permute(ctx.handle, ctypes.c_void_p(states.data_ptr()), nperm))
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    check(lib.gl_poseidon_permute(ctx.handle, ctypes.c_void_p(states.data_ptr()), nperm))
+    ctx.synchronize()
+    perm_per_s = nperm / (time.perf_counter() - t0)
+    roofline["measured_copy_GBs"] = copy_gbs            # torch tensor copy of the same 512 MiB (read + write bytes)
+    roofline["frac_of_measured_copy"] = achieved / copy_gbs
+    ntt["poseidon"] = {"permutations_per_s": perm_per_s, "modular_multiplies_per_s": perm_per_s * 460,
+                       "note": "one 12-word state per lane (k_poseidon_states, 2^23 states): the integer-ALU rate that bounds prove(); "
+                               "18.9 k VALU instructions per permutation (profiles/README.md)"}
+    del data, ref, dst, states
     return roofline, ntt
 
 
