@@ -240,6 +240,16 @@ int gl_fri_query(gl_fri* f, const uint32_t* x_index, uint32_t num_queries, uint8
                  size_t* num_bytes);
 void gl_fri_free(gl_fri* f);
 
+/* A Challenger (iop/challenger.rs:30-153: duplex sponge, challenges pop from the end of the rate) for callers of the
+ * phase API that have no transcript of their own.  Host code.  `gl_challenger_state` exposes sponge_state / input_buffer
+ * the way fri_proof_of_work reads them (fri/prover.rs:127-140), for gl_pow_grind. */
+typedef struct gl_challenger gl_challenger;
+gl_challenger* gl_challenger_new(void);
+int gl_challenger_observe(gl_challenger* c, const uint64_t* h_elements, size_t count);
+int gl_challenger_get_challenges(gl_challenger* c, uint64_t* h_out, size_t count);
+int gl_challenger_state(const gl_challenger* c, uint64_t h_sponge_state[12], uint64_t h_input_buffer[8], uint32_t* input_len);
+void gl_challenger_free(gl_challenger* c);
+
 /* ---- prove() ---------------------------------------------------------------------------------------*/
 /* plonk::prover::prove (plonky2/src/plonk/prover.rs:102-329) from step 4 on, i.e. given the FULL witness matrix
  * `MatrixWitness.wire_values` (iop/witness.rs:256-258) h_wires[num_wires][n] and the public inputs.  Every

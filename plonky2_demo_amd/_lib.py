@@ -106,6 +106,11 @@ SIGNATURES = {
     "gl_fri_query": (c_int, [c_vp, c_vp, c_u32, c_vp, c_sz, ctypes.POINTER(c_sz)]),
     "gl_fri_free": (None, [c_vp]),
     "gl_ctx_capture_intermediates": (c_int, [c_vp, c_int]),
+    "gl_challenger_new": (c_vp, []),
+    "gl_challenger_observe": (c_int, [c_vp, c_vp, c_sz]),
+    "gl_challenger_get_challenges": (c_int, [c_vp, c_vp, c_sz]),
+    "gl_challenger_state": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(c_u32)]),
+    "gl_challenger_free": (None, [c_vp]),
     "gl_prove": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "gl_prove_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "gl_prove_device_hashed": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, ctypes.POINTER(c_vp)]),

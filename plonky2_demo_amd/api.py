@@ -605,6 +605,36 @@ class FriProver:
             pass
 
 
+class Challenger:
+    """plonky2::iop::challenger::Challenger (iop/challenger.rs:30-153), host code."""
+
+    def __init__(self):
+        self.handle = lib.gl_challenger_new()
+
+    def observe_elements(self, xs):
+        a = _u64(np.asarray(xs, dtype=np.uint64).reshape(-1))
+        check(lib.gl_challenger_observe(self.handle, _p(a), a.size))
+
+    def get_n_challenges(self, n):
+        out = np.empty(n, dtype=np.uint64)
+        check(lib.gl_challenger_get_challenges(self.handle, _p(out), n))
+        return [int(x) for x in out]
+
+    def state(self):
+        """(sponge_state[12], input_buffer) as fri_proof_of_work reads them."""
+        st, buf, k = np.empty(12, dtype=np.uint64), np.empty(8, dtype=np.uint64), ctypes.c_uint32()
+        check(lib.gl_challenger_state(self.handle, _p(st), _p(buf), ctypes.byref(k)))
+        return st, buf[: k.value].copy()
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.gl_challenger_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 def pow_grind(sponge_state, input_buffer, min_leading_zeros, ctx=None):
     """fri_proof_of_work (fri/prover.rs:115-160): the smallest valid witness."""
     ctx = _ctx(ctx)

@@ -44,6 +44,29 @@ struct HostChallenger {
     gl_t challenge() { if (nin || !nout) duplexing(); return gl_canon(out[--nout]); }
 };
 
+// C handle of the Challenger for callers of the phase API that have no transcript of their own (C / C++ / Python)
+struct gl_challenger { HostChallenger ch; };
+extern "C" gl_challenger* gl_challenger_new(void) { return new gl_challenger(); }
+extern "C" void gl_challenger_free(gl_challenger* c) { delete c; }
+extern "C" int gl_challenger_observe(gl_challenger* c, const uint64_t* h_elements, size_t count) {
+    GL_REQUIRE(c && (h_elements || !count), GL_ERR_ARG, "gl_challenger_observe: null argument");
+    c->ch.observe_many(h_elements, count);
+    return GL_OK;
+}
+extern "C" int gl_challenger_get_challenges(gl_challenger* c, uint64_t* h_out, size_t count) {
+    GL_REQUIRE(c && (h_out || !count), GL_ERR_ARG, "gl_challenger_get_challenges: null argument");
+    for (size_t i = 0; i < count; i++) h_out[i] = c->ch.challenge();
+    return GL_OK;
+}
+// sponge state and pending inputs, as fri_proof_of_work reads them (fri/prover.rs:127-140): for gl_pow_grind
+extern "C" int gl_challenger_state(const gl_challenger* c, uint64_t h_sponge_state[12], uint64_t h_input_buffer[8], uint32_t* input_len) {
+    GL_REQUIRE(c && h_sponge_state && h_input_buffer && input_len, GL_ERR_ARG, "gl_challenger_state: null argument");
+    for (int i = 0; i < 12; i++) h_sponge_state[i] = c->ch.state[i];
+    for (int i = 0; i < c->ch.nin; i++) h_input_buffer[i] = c->ch.in[i];
+    *input_len = (uint32_t)c->ch.nin;
+    return GL_OK;
+}
+
 // ---- host circuit API ------------------------------------------------------------------------------------------------
 extern "C" int gl_matmul_circuit_build(size_t m, gl_host_circuit** out) {
     GL_REQUIRE(out, GL_ERR_ARG, "null out");

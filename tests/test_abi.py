@@ -64,3 +64,48 @@ def test_host_matmul_circuit_matches_oracle(orc, m):
     ow = oc.witness(a, b, filler_seed=99)
     assert (pis == ow.public_inputs()).all()
     assert (wires == ow.wires()).all()
+
+
+def test_challenger_matches_the_duplex_sponge_model(orc):
+    # gl_challenger_* (iop/challenger.rs:30-153) against a Python model on the oracle's permutation: overwrite-mode duplexing,
+    # challenges popped from the END of the rate, outputs discarded by any new observation; no GPU needed
+    import numpy as np
+    import plonky2_demo_amd as p
+    from oracle_lib import P
+
+    class Model:
+        def __init__(self):
+            self.state, self.inp, self.out = [0] * 12, [], []
+
+        def dup(self):
+            for i, x in enumerate(self.inp):
+                self.state[i] = x
+            self.inp = []
+            self.state = [int(x) for x in orc.poseidon(np.array(self.state, dtype=np.uint64))]
+            self.out = self.state[:8]
+
+        def observe(self, xs):
+            for x in xs:
+                self.out = []
+                self.inp.append(int(x))
+                if len(self.inp) == 8:
+                    self.dup()
+
+        def get(self, k):
+            r = []
+            for _ in range(k):
+                if self.inp or not self.out:
+                    self.dup()
+                r.append(self.out.pop() % P)
+            return r
+
+    ch, mo = p.Challenger(), Model()
+    rng = np.random.default_rng(1)
+    for _ in range(60):
+        xs = rng.integers(0, 2**64, int(rng.integers(0, 20)), dtype=np.uint64)      # non-canonical inputs too
+        ch.observe_elements(xs)
+        mo.observe(xs)
+        k = int(rng.integers(0, 5))
+        assert ch.get_n_challenges(k) == mo.get(k)
+        st, buf = ch.state()
+        assert [int(x) % P for x in st] == [x % P for x in mo.state] and [int(x) for x in buf] == mo.inp

@@ -346,6 +346,27 @@ def test_prove_m128_config5(gpu, orc):
 
 
 # ------------------------------------------------------------------------------- phase-level ABI (SURVEY 8b seam)
+class _ProductChallenger:
+    """The same interface over the library's own gl_challenger_* (for callers without a transcript implementation)."""
+
+    def __init__(self, p):
+        self.ch = p.Challenger()
+
+    def observe(self, xs):
+        self.ch.observe_elements(xs)
+
+    def get(self, k):
+        return self.ch.get_n_challenges(k)
+
+    @property
+    def state(self):
+        return self.ch.state()[0]
+
+    @property
+    def inp(self):
+        return self.ch.state()[1]
+
+
 class _Challenger:
     """iop/challenger.rs:30-153 as the reference-side caller would keep it (here in Python, permutation from the oracle)."""
 
@@ -375,8 +396,8 @@ class _Challenger:
         return r
 
 
-@pytest.mark.parametrize("m", [2, 8, 20])
-def test_phase_api_with_external_transcript_reproduces_the_proof(gpu, orc, m):
+@pytest.mark.parametrize("m,own", [(2, False), (8, False), (20, False), (8, True), (20, True)])
+def test_phase_api_with_external_transcript_reproduces_the_proof(gpu, orc, m, own):
     # every phase entry point of include/plonky2_mi355x.h driven by a caller-side Challenger, in the order of
     # plonk/prover.rs:102-329; the assembled ProofWithPublicInputs bytes equal the oracle's (and gl_prove's)
     p, ctx = gpu
@@ -388,7 +409,7 @@ def test_phase_api_with_external_transcript_reproduces_the_proof(gpu, orc, m):
     op = orc.circuit(m, threads=8).witness(a, b, filler_seed=m).prove(threads=8)
 
     d_w = ctx.alloc(wires.nbytes).upload(wires)
-    ch = _Challenger(orc)
+    ch = _ProductChallenger(p) if own else _Challenger(orc)
     pi_hash = orc.hash_no_pad(pis)
     ch.observe(cd.circuit_digest); ch.observe(pi_hash)
     wires_b = p.PolynomialBatch.from_device(d_w.ptr, 135, n, d.rate_bits, d.cap_height, True)
