@@ -172,26 +172,10 @@ static inline std::vector<unsigned> fri_reduction_arity_bits(const CircuitConfig
     return r;
 }
 
-// Builds the m x m matmul circuit exactly as the demo does, then runs build().
+// build() (circuit_builder.rs:913-1146) for whatever the builder holds: public-input hashing, PublicInputGate, ConstantGate,
+// padding, selectors, constants, sigma polynomials, the constants||sigmas commitment and the circuit digest.
 // `prover_data = false` builds only what the verifier needs (CommonData): no copy constraints, sigmas or commitment.
-static inline CircuitData build_matmul_circuit(size_t m, unsigned threads = 1, bool prover_data = true) {
-    CircuitBuilder b;
-    b.record_copies = prover_data;
-    CircuitData cd;
-    cd.m = m;
-    std::vector<std::vector<Target>> A(m), B(m), C(m);
-    for (size_t i = 0; i < m; i++)
-        for (size_t j = 0; j < m; j++) { A[i].push_back(b.add_virtual_target()); B[i].push_back(b.add_virtual_target()); }
-    for (size_t i = 0; i < m; i++)
-        for (size_t j = 0; j < m; j++) {
-            Target cur = b.constant(0);
-            for (size_t k = 0; k < m; k++) { Target p = b.mul_t(A[i][k], B[k][j]); cur = b.add_t(cur, p); }
-            C[i].push_back(cur);
-        }
-    for (size_t i = 0; i < m; i++)
-        for (size_t j = 0; j < m; j++) { b.public_inputs.push_back(A[i][j]); b.public_inputs.push_back(B[i][j]); b.public_inputs.push_back(C[i][j]); }
-    for (size_t i = 0; i < m; i++) for (size_t j = 0; j < m; j++) { cd.a_targets.push_back(A[i][j]); cd.b_targets.push_back(B[i][j]); }
-
+static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned threads, bool prover_data) {
     // ---- build() (circuit_builder.rs:913-1146) ----
     const CircuitConfig& cfg = b.config;
     auto pi_hash = b.hash_public_inputs(b.public_inputs);
@@ -263,7 +247,7 @@ static inline CircuitData build_matmul_circuit(size_t m, unsigned threads = 1, b
     for (auto g : gates) cm.num_gate_constraints = std::max(cm.num_gate_constraints, gate_num_constraints(g));
     cm.num_partial_products = (cfg.num_routed_wires + cm.quotient_degree_factor - 1) / cm.quotient_degree_factor - 1;   // partial_products.rs:40-47
     cm.num_public_inputs = b.public_inputs.size();
-    if (!prover_data) { cd.pi_row = pi_row; return cd; }
+    if (!prover_data) { cd.pi_row = pi_row; return; }
     // subgroup, k_is (cosets.rs:9-24), sigma polynomials (permutation_argument.rs)
     cd.subgroup.resize(degree);
     { u64 g = primitive_root_of_unity(degree_bits), x = 1; for (size_t i = 0; i < degree; i++) { cd.subgroup[i] = x; x = mul(x, g); } }
@@ -316,6 +300,48 @@ static inline CircuitData build_matmul_circuit(size_t m, unsigned threads = 1, b
     cd.arith_ops = b.arith_ops;
     cd.poseidon_rows = b.poseidon_rows;
     cd.pi_row = pi_row;
+}
+
+// Builds the m x m matmul circuit exactly as the demo does (plonky2/src/bin/matrix_mul.rs:25-67), then runs build().
+static inline CircuitData build_matmul_circuit(size_t m, unsigned threads = 1, bool prover_data = true) {
+    CircuitBuilder b;
+    b.record_copies = prover_data;
+    CircuitData cd;
+    cd.m = m;
+    std::vector<std::vector<Target>> A(m), B(m), C(m);
+    for (size_t i = 0; i < m; i++)
+        for (size_t j = 0; j < m; j++) { A[i].push_back(b.add_virtual_target()); B[i].push_back(b.add_virtual_target()); }
+    for (size_t i = 0; i < m; i++)
+        for (size_t j = 0; j < m; j++) {
+            Target cur = b.constant(0);
+            for (size_t k = 0; k < m; k++) { Target p = b.mul_t(A[i][k], B[k][j]); cur = b.add_t(cur, p); }
+            C[i].push_back(cur);
+        }
+    for (size_t i = 0; i < m; i++)
+        for (size_t j = 0; j < m; j++) { b.public_inputs.push_back(A[i][j]); b.public_inputs.push_back(B[i][j]); b.public_inputs.push_back(C[i][j]); }
+    for (size_t i = 0; i < m; i++) for (size_t j = 0; j < m; j++) { cd.a_targets.push_back(A[i][j]); cd.b_targets.push_back(B[i][j]); }
+    finish_build(b, cd, threads, prover_data);
+    return cd;
+}
+
+// Two more circuits over the same gate set, to exercise circuit shapes the matmul family never produces (tests only):
+//   kind 1 "hash only": `param` inputs, all registered as public inputs -> gates {Noop, Constant, PublicInput, Poseidon}
+//                       (no ArithmeticGate; selector groups {0,1,2} | {3})
+//   kind 2 "chain":     x0, x1 inputs, `param` steps x_{i+2} = x_{i+1} x_i + x_i, NO public inputs -> gates {Noop, Constant,
+//                       PublicInput, Arithmetic}: one selector group (num_selectors = 1, no UNUSED factor in the filters)
+static inline CircuitData build_test_circuit(int kind, size_t param, unsigned threads = 1, bool prover_data = true) {
+    CircuitBuilder b;
+    b.record_copies = prover_data;
+    CircuitData cd;
+    cd.m = 0;
+    if (kind == 1) {
+        for (size_t i = 0; i < param; i++) { Target t = b.add_virtual_target(); cd.a_targets.push_back(t); b.public_inputs.push_back(t); }
+    } else {
+        Target x0 = b.add_virtual_target(), x1 = b.add_virtual_target();
+        cd.a_targets = {x0, x1};
+        for (size_t i = 0; i < param; i++) { Target x2 = b.arithmetic(1, 1, x1, x0, x0); x0 = x1; x1 = x2; }
+    }
+    finish_build(b, cd, threads, prover_data);
     return cd;
 }
 
@@ -375,8 +401,9 @@ static inline Witness generate_witness(const CircuitData& cd, const std::vector<
     auto rep = [&](const Target& t) { return cd.representative[cd.target_index(t)]; };
     auto put = [&](const Target& t, u64 v) { size_t r = rep(t); assert(!set[r] || canon(val[r]) == canon(v)); val[r] = canon(v); set[r] = 1; };
     auto get = [&](const Target& t) { size_t r = rep(t); assert(set[r]); return val[r]; };
-    assert(a.size() == cd.m * cd.m && b.size() == cd.m * cd.m);
-    for (size_t i = 0; i < a.size(); i++) { put(cd.a_targets[i], a[i]); put(cd.b_targets[i], b[i]); }
+    assert(a.size() == cd.a_targets.size() && b.size() == cd.b_targets.size());
+    for (size_t i = 0; i < a.size(); i++) put(cd.a_targets[i], a[i]);
+    for (size_t i = 0; i < b.size(); i++) put(cd.b_targets[i], b[i]);
     for (auto& cw : cd.constant_wires) put(Target::wire(cd.constant_row, cw.first), cw.second);
     for (auto& op : cd.arith_ops) {                      // ArithmeticBaseGenerator (arithmetic_base.rs:203-218)
         u64 m0 = get(Target::wire(op.row, 4 * op.slot)), m1 = get(Target::wire(op.row, 4 * op.slot + 1)), ad = get(Target::wire(op.row, 4 * op.slot + 2));

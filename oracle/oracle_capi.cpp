@@ -187,6 +187,16 @@ struct OrcProof { Proof proof; ProverTrace trace; std::vector<uint8_t> bytes; };
 void* orc_circuit_new(size_t m, unsigned threads) { return new CircuitData(build_matmul_circuit(m, threads)); }
 // CommonCircuitData only (what verify() needs besides the cap and the digest): cheap even for m = 128
 void* orc_circuit_new_verifier_only(size_t m) { return new CircuitData(build_matmul_circuit(m, 1, false)); }
+// test circuits over the same gate set (gl_circuit.hpp build_test_circuit): kind 1 hash-only, kind 2 arithmetic chain without PIs
+void* orc_circuit_new_kind(int kind, size_t param, unsigned threads) { return new CircuitData(build_test_circuit(kind, param, threads)); }
+// what a gl_circuit_desc needs beyond orc_circuit_info: per gate (selector index, group start, group end), k_is, FRI arities
+size_t orc_circuit_selector_groups(const void* c, u64* out /* [num_gates][3] */) {
+    const CircuitData* cd = (const CircuitData*)c; const SelectorsInfo& si = cd->common.selectors;
+    for (size_t i = 0; i < si.gates.size(); i++) { size_t g = si.selector_indices[i]; out[3 * i] = g; out[3 * i + 1] = si.groups[g].first; out[3 * i + 2] = si.groups[g].second; }
+    return si.gates.size();
+}
+void orc_circuit_k_is(const void* c, u64* out80) { const CircuitData* cd = (const CircuitData*)c; for (size_t i = 0; i < cd->common.k_is.size(); i++) out80[i] = canon(cd->common.k_is[i]); }
+size_t orc_circuit_num_inputs(const void* c, size_t* nb) { const CircuitData* cd = (const CircuitData*)c; if (nb) *nb = cd->b_targets.size(); return cd->a_targets.size(); }
 // verify ProofWithPublicInputs bytes against VerifierOnlyCircuitData = (constants_sigmas_cap[2^cap_height][4], circuit_digest[4])
 // 0 = accepted, 1 = rejected, 2 = malformed bytes
 static thread_local const char* g_verify_msg2 = "";
@@ -230,8 +240,8 @@ size_t orc_circuit_gate_order(const void* c, uint8_t* out) {
     return cd->common.selectors.gates.size();
 }
 void* orc_witness_new(const void* c, const u64* a, const u64* b, u64 filler_seed) {
-    const CircuitData* cd = (const CircuitData*)c; size_t mm = cd->m * cd->m;
-    return new Witness(generate_witness(*cd, std::vector<u64>(a, a + mm), std::vector<u64>(b, b + mm), filler_seed));
+    const CircuitData* cd = (const CircuitData*)c; const size_t na = cd->a_targets.size(), nb = cd->b_targets.size();
+    return new Witness(generate_witness(*cd, std::vector<u64>(a, a + na), std::vector<u64>(b, b + nb), filler_seed));
 }
 void orc_witness_free(void* w) { delete (Witness*)w; }
 void orc_witness_wires(const void* w, u64* out) {

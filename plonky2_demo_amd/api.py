@@ -547,6 +547,62 @@ class CircuitData:
             pass
 
 
+class GenericCircuitData:
+    """Prover + verifier for ANY circuit over the demo's gate set, given what CircuitBuilder::build() produces: the descriptor
+    (CommonCircuitData) and the constants || sigmas value columns (gl_circuit_create)."""
+
+    def __init__(self, desc, constants_sigmas, ctx=None):
+        self.ctx, self.desc = _ctx(ctx), desc
+        self.n = 1 << desc.degree_bits
+        cs = _u64(constants_sigmas)
+        if cs.shape != (desc.num_constants + 80, self.n):
+            raise ValueError("constants_sigmas must be [num_constants + 80][n]")
+        h = ctypes.c_void_p()
+        check(lib.gl_circuit_create(self.ctx.handle, ctypes.byref(desc), _p(cs), ctypes.byref(h)))
+        self.handle = h.value
+
+    @property
+    def circuit_digest(self):
+        out = np.empty(4, dtype=np.uint64)
+        check(lib.gl_circuit_digest(self.handle, _p(out)))
+        return out
+
+    @property
+    def constants_sigmas_cap(self):
+        out = np.empty((1 << self.desc.cap_height, 4), dtype=np.uint64)
+        check(lib.gl_circuit_constants_sigmas_cap(self.handle, _p(out)))
+        return out
+
+    def prove(self, wires, public_inputs):
+        wires, pis = _u64(wires), _u64(public_inputs)
+        if wires.shape != (135, self.n):
+            raise ValueError("wire matrix must be [135][n]")
+        if pis.size == 0:
+            pis = np.zeros(1, dtype=np.uint64)[:0]
+        h = ctypes.c_void_p()
+        keep = np.zeros(1, dtype=np.uint64) if pis.size == 0 else pis          # a valid pointer even for zero public inputs
+        check(lib.gl_prove(self.ctx.handle, self.handle, _p(wires), _p(keep), pis.size, ctypes.byref(h)))
+        return Proof(h.value, self.n)
+
+    def verify(self, proof):
+        by = proof.to_bytes() if hasattr(proof, "to_bytes") else proof
+        buf = np.frombuffer(bytes(by), dtype=np.uint8)
+        st = lib.gl_verify(ctypes.byref(self.desc), _p(self.constants_sigmas_cap), _p(self.circuit_digest), _p(buf), buf.size)
+        if st == _lib.GL_OK:
+            return True, ""
+        if st == _lib.GL_ERR_VERIFY:
+            return False, (lib.gl_last_error() or b"").decode()
+        check(st)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.gl_circuit_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class CircuitView:
     """The same device-resident CircuitData used from another context (stream) of the same device."""
 

@@ -125,6 +125,9 @@ class Oracle:
     def circuit(self, m, threads=1, verifier_only=False):
         return OracleCircuit(self, m, threads, verifier_only)
 
+    def circuit_of_kind(self, kind, param, threads=1):
+        return OracleCircuit.of_kind(self, kind, param, threads)
+
 
 class OracleMerkle:
     def __init__(self, o, leaves, cap_height):
@@ -221,6 +224,53 @@ class OracleCircuit:
         self.info = dict(zip(self.INFO, (int(x) for x in info)))
         self.n = 1 << self.info["degree_bits"]
 
+    @classmethod
+    def of_kind(cls, o, kind, param, threads=1):
+        """gl_circuit.hpp build_test_circuit: kind 1 = hash-only (param public inputs), kind 2 = arithmetic chain, no PIs."""
+        self = cls.__new__(cls)
+        self.o, self.m = o, 0
+        lib = o.lib
+        for fn in ("orc_circuit_new_kind", "orc_witness_new", "orc_witness_from_matrix", "orc_prove"):
+            getattr(lib, fn).restype = _vp
+        for fn in ("orc_proof_bytes", "orc_proof_challenges", "orc_proof_query_indices", "orc_witness_public_inputs", "orc_circuit_gate_order",
+                   "orc_circuit_selector_groups", "orc_circuit_num_inputs"):
+            getattr(lib, fn).restype = _sz
+        lib.orc_verify_message.restype = ctypes.c_char_p
+        lib.orc_verify_bytes_message.restype = ctypes.c_char_p
+        self.h = _vp(lib.orc_circuit_new_kind(ctypes.c_int(kind), _sz(param), _u32(threads)))
+        info = np.zeros(12, dtype=np.uint64)
+        lib.orc_circuit_info(self.h, _p(info))
+        self.info = dict(zip(self.INFO, (int(x) for x in info)))
+        self.n = 1 << self.info["degree_bits"]
+        return self
+
+    def product_desc(self):
+        """The gl_circuit_desc (plonky2_demo_amd._lib.CircuitDesc) of this circuit, for gl_circuit_create / gl_verify."""
+        from plonky2_demo_amd._lib import CircuitDesc
+        lib = self.o.lib
+        lib.orc_circuit_selector_groups.restype = _sz
+        d = CircuitDesc()
+        i = self.info
+        d.degree_bits, d.num_wires, d.num_routed_wires, d.num_constants = i["degree_bits"], 135, 80, i["num_constants"]
+        d.num_selectors, d.num_challenges, d.quotient_degree_factor = i["num_selectors"], 2, 8
+        d.rate_bits, d.cap_height, d.proof_of_work_bits, d.num_query_rounds = 3, 4, 16, 28
+        d.num_fri_rounds = i["num_fri_rounds"]
+        for r in range(d.num_fri_rounds):
+            d.fri_arity_bits[r] = 4
+        d.num_public_inputs = i["num_public_inputs"]
+        order = self.gate_order()
+        d.num_gates = len(order)
+        groups = np.zeros(3 * 8, dtype=np.uint64)
+        lib.orc_circuit_selector_groups(self.h, _p(groups))
+        for g, t in enumerate(order):
+            d.gate_types[g] = t
+            d.gate_selector_index[g], d.gate_group_start[g], d.gate_group_end[g] = int(groups[3 * g]), int(groups[3 * g + 1]), int(groups[3 * g + 2])
+        k = np.zeros(80, dtype=np.uint64)
+        lib.orc_circuit_k_is(self.h, _p(k))
+        for j in range(80):
+            d.k_is[j] = int(k[j])
+        return d
+
     @property
     def digest(self):
         out = np.empty(4, dtype=np.uint64)
@@ -269,7 +319,12 @@ class OracleWitness:
     def __init__(self, circuit, a, b, seed):
         self.c = circuit
         lib = circuit.o.lib
-        assert a.size == circuit.m ** 2 and b.size == circuit.m ** 2
+        lib.orc_circuit_num_inputs.restype = _sz
+        nb = ctypes.c_size_t()
+        na = lib.orc_circuit_num_inputs(circuit.h, ctypes.byref(nb))
+        assert a.size == na and b.size == nb.value, (a.size, b.size, na, nb.value)
+        if b.size == 0:
+            b = np.zeros(1, dtype=np.uint64)           # a valid pointer for circuits without second-operand targets
         self.h = _vp(lib.orc_witness_new(circuit.h, _p(a), _p(b), _u64(seed)))
 
     def wires(self):

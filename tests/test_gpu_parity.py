@@ -586,3 +586,21 @@ def test_gpu_proof_regression_hashes(gpu):
         assert pr.challenges()["pow_witness"] == w["pow_witness"]
         assert hashlib.sha256(pr.to_bytes()).hexdigest() == w["sha256"]
         assert cd.verify(pr) == (True, "")
+
+
+@pytest.mark.parametrize("kind,param", [(1, 16), (1, 5), (1, 40), (2, 50), (2, 400), (2, 3000)])
+def test_generic_circuits_over_the_same_gate_set(gpu, orc, kind, param):
+    # gl_circuit_create + gl_prove are not tied to the matmul layout: circuits built by the oracle's generic CircuitBuilder with
+    # other gate subsets (no ArithmeticGate / no PoseidonGate and zero public inputs / no NoopGate), one or two selector groups
+    p, ctx = gpu
+    oc = orc.circuit_of_kind(kind, param, threads=8)
+    a = rand_field(100 * kind + param, param if kind == 1 else 2)
+    w = oc.witness(a, np.zeros(0, dtype=np.uint64), filler_seed=kind)
+    op = w.prove(threads=8)
+    cd = p.GenericCircuitData(oc.product_desc(), oc.constants_sigmas())
+    assert (cd.circuit_digest == oc.digest).all() and (cd.constants_sigmas_cap == oc.constants_sigmas_cap).all()
+    gp = cd.prove(w.wires(), w.public_inputs())
+    assert gp.challenges() == op.challenges()
+    assert gp.to_bytes() == op.to_bytes()
+    assert cd.verify(gp) == (True, "")
+    assert oc.verify_bytes(gp.to_bytes(), cd.constants_sigmas_cap, cd.circuit_digest)[0]
