@@ -588,7 +588,7 @@ def test_gpu_proof_regression_hashes(gpu):
         assert cd.verify(pr) == (True, "")
 
 
-@pytest.mark.parametrize("kind,param", [(1, 16), (1, 5), (1, 40), (2, 50), (2, 400), (2, 3000)])
+@pytest.mark.parametrize("kind,param", [(1, 16), (1, 5), (1, 40), (1, 4000), (2, 50), (2, 400), (2, 3000), (2, 200000)])
 def test_generic_circuits_over_the_same_gate_set(gpu, orc, kind, param):
     # gl_circuit_create + gl_prove are not tied to the matmul layout: circuits built by the oracle's generic CircuitBuilder with
     # other gate subsets (no ArithmeticGate / no PoseidonGate and zero public inputs / no NoopGate), one or two selector groups
