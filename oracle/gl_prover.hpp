@@ -75,6 +75,23 @@ static inline Ext2 eval_extpoly_ext(const std::vector<Ext2>& coeffs, Ext2 z) {
     return acc;
 }
 
+// quotient_chunk_products / partial_products_and_z_gx (util/partial_products.rs:13-37)
+static inline std::vector<u64> quotient_chunk_products(const std::vector<u64>& quotient_values, size_t max_degree) {
+    std::vector<u64> out;
+    for (size_t c = 0; c < quotient_values.size(); c += max_degree) {
+        u64 p = 1;
+        for (size_t j = c; j < std::min(quotient_values.size(), c + max_degree); j++) p = mul(p, quotient_values[j]);
+        out.push_back(p);
+    }
+    return out;
+}
+static inline std::vector<u64> partial_products_and_z_gx(u64 z_x, const std::vector<u64>& chunk_products) {
+    std::vector<u64> res;
+    u64 acc = z_x;
+    for (u64 c : chunk_products) { acc = mul(acc, c); res.push_back(acc); }
+    return res;
+}
+
 // wires_permutation_partial_products_and_zs (prover.rs:359-416) for one challenge: returns 10 columns
 // [pp_0 .. pp_8, Z]
 static inline std::vector<std::vector<u64>> partial_products_and_z(const CircuitData& cd, const Witness& w, u64 beta, u64 gamma, unsigned threads) {
@@ -90,18 +107,15 @@ static inline std::vector<std::vector<u64>> partial_products_and_z(const Circuit
             num[j] = add(add(wv, mul(beta, mul(cm.k_is[j], x))), gamma);
             den[j] = add(add(wv, mul(beta, cd.constants_sigmas[nc + j][i])), gamma);
         }
-        std::vector<u64> inv_den = batch_inverse(den);
-        for (size_t c = 0; c < chunks; c++) {
-            u64 p = 1;
-            for (size_t j = c * deg; j < std::min(R, (c + 1) * deg); j++) p = mul(p, mul(num[j], inv_den[j]));
-            chunk_prod[i][c] = p;
-        }
+        std::vector<u64> inv_den = batch_inverse(den), quotient_values(R);
+        for (size_t j = 0; j < R; j++) quotient_values[j] = mul(num[j], inv_den[j]);
+        chunk_prod[i] = quotient_chunk_products(quotient_values, deg);
     });
     std::vector<std::vector<u64>> cols(chunks, std::vector<u64>(n));
     u64 z_x = 1;
     for (size_t i = 0; i < n; i++) {
-        u64 acc = z_x;
-        for (size_t c = 0; c < chunks; c++) { acc = mul(acc, chunk_prod[i][c]); cols[c][i] = acc; }
+        std::vector<u64> pps_and_z_gx = partial_products_and_z_gx(z_x, chunk_prod[i]);
+        for (size_t c = 0; c < chunks; c++) cols[c][i] = pps_and_z_gx[c];
         std::swap(z_x, cols[chunks - 1][i]);          // prover.rs:402-410: store Z(x), carry Z(gx)
     }
     return cols;

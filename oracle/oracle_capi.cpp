@@ -184,6 +184,23 @@ void orc_batch_level(const void* b, size_t level, u64* out) { write_digests(((co
 // ---- matmul circuit / witness / prover / verifier ------------------------------------------------------
 struct OrcProof { Proof proof; ProverTrace trace; std::vector<uint8_t> bytes; };
 
+// util/partial_products.rs helpers, for the reference's own test vector (partial_products.rs:114-146)
+size_t orc_quotient_chunk_products(const u64* v, size_t n, size_t max_degree, u64* out) {
+    auto r = quotient_chunk_products(std::vector<u64>(v, v + n), max_degree);
+    for (size_t i = 0; i < r.size(); i++) out[i] = canon(r[i]);
+    return r.size();
+}
+void orc_partial_products_and_z_gx(u64 z_x, const u64* chunks, size_t n, u64* out) {
+    auto r = partial_products_and_z_gx(z_x, std::vector<u64>(chunks, chunks + n));
+    for (size_t i = 0; i < r.size(); i++) out[i] = canon(r[i]);
+}
+// check_partial_products over the base field: out gets ceil(n / max_degree) constraint values
+size_t orc_check_partial_products(const u64* num, const u64* den, size_t n, const u64* partials, size_t nparts, u64 z_x, u64 z_gx, size_t max_degree, u64* out) {
+    std::vector<u64> res;
+    check_partial_products<u64>(num, den, n, partials, nparts, z_x, z_gx, max_degree, res);
+    for (size_t i = 0; i < res.size(); i++) out[i] = canon(res[i]);
+    return res.size();
+}
 void* orc_circuit_new(size_t m, unsigned threads) { return new CircuitData(build_matmul_circuit(m, threads)); }
 // CommonCircuitData only (what verify() needs besides the cap and the digest): cheap even for m = 128
 void* orc_circuit_new_verifier_only(size_t m) { return new CircuitData(build_matmul_circuit(m, 1, false)); }

@@ -223,3 +223,31 @@ def test_proof_regression_hashes(orc):
         assert [int(x) for x in oc.digest] == w["digest"]
         assert len(pr.to_bytes()) == w["bytes"] and pr.challenges()["pow_witness"] == w["pow_witness"]
         assert hashlib.sha256(pr.to_bytes()).hexdigest() == w["sha256"]
+
+
+def test_partial_products_reference_vector(orc):
+    # the reference's own test (plonky2/src/util/partial_products.rs:114-146): v = [1..6], denominators = 1, Z(x) = 1, Z(gx) = 720
+    import ctypes
+    lib = orc.lib
+    lib.orc_quotient_chunk_products.restype = ctypes.c_size_t
+    lib.orc_check_partial_products.restype = ctypes.c_size_t
+    u = lambda xs: np.array(xs, dtype=np.uint64)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    v, ones = u([1, 2, 3, 4, 5, 6]), u([1] * 6)
+    for max_degree, chunks, pps_z in ((2, [2, 12, 30], [2, 24, 720]), (3, [6, 120], [6, 720])):
+        out = np.zeros(8, dtype=np.uint64)
+        k = lib.orc_quotient_chunk_products(vp(v), ctypes.c_size_t(6), ctypes.c_size_t(max_degree), vp(out))
+        assert out[:k].tolist() == chunks
+        acc = np.zeros(k, dtype=np.uint64)
+        lib.orc_partial_products_and_z_gx(ctypes.c_uint64(1), vp(u(chunks)), ctypes.c_size_t(k), vp(acc))
+        assert acc.tolist() == pps_z
+        pps = u(pps_z[:-1])                                   # num_partial_products = ceil(6 / max_degree) - 1
+        assert len(pps) == -(-6 // max_degree) - 1
+        chk = np.ones(8, dtype=np.uint64)
+        c = lib.orc_check_partial_products(vp(v), vp(ones), ctypes.c_size_t(6), vp(pps), ctypes.c_size_t(len(pps)), ctypes.c_uint64(1),
+                                           ctypes.c_uint64(720), ctypes.c_size_t(max_degree), vp(chk))
+        assert c == len(chunks) and chk[:c].tolist() == [0] * c
+        # and a wrong Z(gx) is caught
+        lib.orc_check_partial_products(vp(v), vp(ones), ctypes.c_size_t(6), vp(pps), ctypes.c_size_t(len(pps)), ctypes.c_uint64(1),
+                                       ctypes.c_uint64(721), ctypes.c_size_t(max_degree), vp(chk))
+        assert any(int(x) for x in chk[:c])
