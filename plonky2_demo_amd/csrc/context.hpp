@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <unordered_map>
 #include <string>
@@ -52,8 +53,8 @@ struct gl_ctx {
     bool own_stream = false;
     gl_t* tw_local[2] = {nullptr, nullptr};                       // w_4096^e forward / inverse
     std::map<std::pair<gl_t, gl_t>, GlPowTable> pow_tables;       // (base, scale) -> table
-    std::map<std::pair<gl_t, uint32_t>, gl_t*> pass_tables;        // (w_N, lgN1) -> inter-pass twiddles in column-pass output order
-    int get_pass_table(gl_t w, uint32_t lgN1, uint32_t lgN2, const gl_t** out);
+    std::map<std::tuple<gl_t, gl_t, uint32_t>, gl_t*> pass_tables; // (w_N, scale, lgN1) -> scale * inter-pass twiddles in column-pass output order
+    int get_pass_table(gl_t w, gl_t scale, uint32_t lgN1, uint32_t lgN2, const gl_t** out);
     gl_t* scratch = nullptr;
     size_t scratch_elems = 0;
     size_t scratch_target = size_t(1) << 24;                      // 128 MiB: stays Infinity-Cache resident

@@ -312,12 +312,13 @@ __global__ void ntt_power_table(gl_t base, gl_t scale, gl_t* out_lo, gl_t* out_h
     if (j < lo_len) out_lo[j] = gl_canon(gl_exp(base, j));
     if (j < hi_len) out_hi[j] = gl_canon(gl_mul(scale, gl_exp(base, (uint64_t)j << NTT_SPLIT_LOG)));
 }
-// out[(k1 << lgN2) + i2] = base^(i2 * k1): the inter-pass twiddles in the order the column pass stores its output
-__global__ void ntt_pass_table(gl_t base, gl_t* out, uint32_t lgN1, uint32_t lgN2) {
+// out[(k1 << lgN2) + i2] = scale * base^(i2 * k1): the inter-pass twiddles in the order the column pass stores its output
+// (scale = the 1/N of an inverse transform, folded in here so that the row pass needs no multiply for it)
+__global__ void ntt_pass_table(gl_t base, gl_t scale, gl_t* out, uint32_t lgN1, uint32_t lgN2) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= (1u << (lgN1 + lgN2))) return;
     const uint32_t k1 = j >> lgN2, i2 = j & ((1u << lgN2) - 1);
-    out[j] = gl_canon(gl_exp(base, (uint64_t)i2 * k1));
+    out[j] = gl_canon(gl_mul(scale, gl_exp(base, (uint64_t)i2 * k1)));
 }
 __global__ void ntt_root_table(gl_t base, gl_t* out, uint32_t len) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;

@@ -64,14 +64,14 @@ int gl_ctx::get_pow_table(gl_t base, gl_t scale, uint32_t hi_len, GlPowTable* ou
     return GL_OK;
 }
 
-int gl_ctx::get_pass_table(gl_t w, uint32_t lgN1, uint32_t lgN2, const gl_t** out) {
-    auto key = std::make_pair(w, lgN1);
+int gl_ctx::get_pass_table(gl_t w, gl_t scale, uint32_t lgN1, uint32_t lgN2, const gl_t** out) {
+    auto key = std::make_tuple(w, scale, lgN1);
     auto it = pass_tables.find(key);
     if (it != pass_tables.end()) { *out = it->second; return GL_OK; }
     const size_t N = size_t(1) << (lgN1 + lgN2);
     gl_t* t = nullptr;
     GL_CHECK_HIP(hipMalloc((void**)&t, N * sizeof(gl_t)));
-    hipLaunchKernelGGL(ntt_pass_table, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w, t, lgN1, lgN2);
+    hipLaunchKernelGGL(ntt_pass_table, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, w, scale, t, lgN1, lgN2);
     GL_CHECK_HIP(hipGetLastError());
     pass_tables[key] = t;
     *out = t;
@@ -372,7 +372,13 @@ int gl_ntt_run(gl_ctx* c, const gl_t* src, uint64_t src_stride, uint32_t n_in, g
     // the N inter-pass twiddles as a table in output order (8 N bytes, shared by every polynomial of every batch): worth it
     // when several polynomials share it
     const gl_t* tw_pass = nullptr;
-    if (lgN <= 22 && batch >= 4) GL_TRY(c->get_pass_table(w, lgN1, lgN2, &tw_pass));
+    gl_t row_post_const = gl_canon(post_const);
+    if (lgN <= 22 && batch >= 4) {
+        // a scalar output factor (the 1/N of an inverse transform) rides in the table: no multiply for it in the row pass
+        const gl_t scale = post_shift ? gl_t(1) : row_post_const;
+        GL_TRY(c->get_pass_table(w, scale, lgN1, lgN2, &tw_pass));
+        if (!post_shift) row_post_const = 1;
+    }
     size_t want = c->scratch_target > N ? c->scratch_target : N;
     if (want > (size_t)batch * N) want = (size_t)batch * N;
     GL_TRY(c->ensure_scratch(want));
@@ -391,7 +397,7 @@ int gl_ntt_run(gl_ctx* c, const gl_t* src, uint64_t src_stride, uint32_t n_in, g
         r.src = c->scratch; r.src_stride = N;
         r.dst = dst + (uint64_t)b0 * dst_stride; r.dst_stride = dst_stride;
         r.batch = nb; r.lgN1 = lgN1; r.lgN2 = lgN2; r.n_in = (uint32_t)N;
-        if (post_shift) { r.post_lo = post.lo; r.post_hi = post.hi; } else r.post_const = gl_canon(post_const);
+        if (post_shift) { r.post_lo = post.lo; r.post_hi = post.hi; } else r.post_const = row_post_const;
         GL_TRY(dispatch_row(c, (int)lgN2, inverse, r, dim3((1u << lgN1) / TB, nb)));
     }
     return GL_OK;
