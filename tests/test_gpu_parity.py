@@ -153,6 +153,26 @@ def test_poseidon_known_answers(gpu, orc, golden):
     assert (p.poseidon(r) == orc.poseidon(r)).all()
 
 
+def test_poseidon_extreme_and_non_canonical_states(gpu, orc):
+    # every carry / borrow path of the GPU permutation (32-bit-half MDS accumulators, the three-round groups, reduce96/128):
+    # states built from the edge values 0, 1, 2^32-1, 2^32, p-1, p, p+1, 2^64-1 in all positions plus random mixes of them
+    p, ctx = gpu
+    edge = np.array([0, 1, 2**32 - 1, 2**32, 2**32 + 1, P - 1, P, P + 1, 2**63, 2**64 - 2**32, 2**64 - 1], dtype=np.uint64)
+    rng = np.random.default_rng(12)
+    states = [np.full(12, e, dtype=np.uint64) for e in edge]
+    for _ in range(400):
+        states.append(edge[rng.integers(0, len(edge), 12)])
+    for k in range(12):
+        st = np.zeros(12, dtype=np.uint64); st[k] = 2**64 - 1; states.append(st)
+    states = np.stack(states)
+    got, want = p.poseidon(states), orc.poseidon(states)
+    assert (got == want).all()
+    # the cooperative (16 lanes per state) and fused-top variants see the same values through tiny Merkle trees
+    leaves = states[:256, :8].copy()
+    for cap_height in (0, 4):
+        assert (p.MerkleTree(leaves, cap_height).cap == orc.merkle(leaves, cap_height).cap).all()
+
+
 @pytest.mark.parametrize("ln", [1, 3, 4, 5, 7, 8, 9, 16, 17, 32, 84, 135])
 def test_hash_or_noop_rows(gpu, orc, ln):
     p, ctx = gpu
