@@ -103,6 +103,22 @@ def test_ntt_non_canonical_input(gpu, orc):
     assert (p.ifft(x) == orc.ifft(x)).all()
 
 
+def test_ntt_extreme_values(gpu, orc):
+    # inputs made only of the edge values (0, 1, 2^32 +- 1, p - 1, p, p + 1, 2^64 - 1): every carry / borrow correction of the
+    # butterflies, shift twiddles and table multiplies, single-pass and two-pass sizes, plain, inverse and zero-padded coset LDE
+    p, ctx = gpu
+    edge = np.array([0, 1, 2**32 - 1, 2**32, 2**32 + 1, P - 1, P, P + 1, 2**63, 2**64 - 2**32, 2**64 - 1], dtype=np.uint64)
+    rng = np.random.default_rng(3)
+    for lg in (4, 10, 13, 16):
+        x = edge[rng.integers(0, len(edge), (5, 1 << lg))]
+        x[0, :] = 2**64 - 1
+        x[1, :] = P - 1
+        assert (p.fft(x) == orc.fft(x)).all(), lg
+        assert (p.ifft(x) == orc.ifft(x)).all(), lg
+        if lg <= 13:
+            assert (p.lde_onto_coset(x, 3) == orc.lde(x, 3, threads=4)).all(), lg
+
+
 def test_ntt_2_20_against_oracle_and_round_trip(gpu, orc):
     # BASELINE config 2: 2^20-point forward + inverse, bit-exact vs field::fft on B = 2; properties on B = 8
     p, ctx = gpu
