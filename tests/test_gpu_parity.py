@@ -311,6 +311,24 @@ def test_prove_is_byte_identical_to_the_oracle(gpu, orc, m):
     assert op.verify()[0]                      # ... and the native verifier restatement accepts those bytes' proof
 
 
+def test_prove_full_range_operands_and_edge_values(gpu, orc):
+    # matrix entries over the whole field (the demo draws u32) and made of edge values: more carry paths in the permutation
+    # argument, the quotient and FRI; still byte-identical to the oracle
+    p, ctx = gpu
+    m = 8
+    hc, oc = p.MatmulCircuit(m), orc.circuit(m, threads=8)
+    cd = hc.build()
+    edge = np.array([0, 1, 2**32 - 1, 2**32, P - 1, P - 2, 2**63, (P - 1) // 2], dtype=np.uint64)
+    rng = np.random.default_rng(8)
+    for a, b in ((rand_field(801, m * m), rand_field(802, m * m)), (edge[rng.integers(0, len(edge), m * m)], edge[rng.integers(0, len(edge), m * m)])):
+        wires, pis = hc.witness(a, b, filler_seed=5)
+        ow = oc.witness(a, b, filler_seed=5)
+        assert (ow.wires() == wires).all()
+        gp, op = cd.prove(wires, pis), ow.prove(threads=8)
+        assert gp.to_bytes() == op.to_bytes()
+        assert cd.verify(gp) == (True, "")
+
+
 def test_prove_readme_instance(gpu, orc):
     p, ctx = gpu
     hc = p.MatmulCircuit(2)
