@@ -364,7 +364,7 @@ extern "C" int gl_fri_combine(gl_ctx* ctx, const gl_circuit* cir, const gl_batch
         gl_t* Fa = d_F.as<gl_t>(); gl_t* Fb = Fa + n;
         gl_t* Qa = f->coef->as<gl_t>(); gl_t* Qb = Qa + n;
         const gl2_t shift = gl2_canon(gl2_mul(fri_alpha, fri_alpha));     // alpha^(#polys of batch 1) (reducing.rs:103-106)
-        const unsigned gb = (unsigned)((n + 255) / 256), sb = (nseg + 63) / 64;
+        const unsigned gb = (unsigned)((n + 63) / 64), sb = (nseg + 63) / 64;      // k_fri_combine: 64 coefficients per workgroup
         ctx->timing_begin("reduce batch + divide by linear");
         // batch 0: all polynomials at zeta
         hipLaunchKernelGGL(k_fri_combine, dim3(gb), dim3(256), 0, st, d_cols.as<const gl_t*>(), d_apow.as<gl_t>(), (uint32_t)nopen, (uint32_t)n, Fa, Fb);
@@ -598,7 +598,8 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     const uint32_t lgn = d.degree_bits, ncap = 4u << d.cap_height;
     hipStream_t st = ctx->stream;
     std::unique_ptr<gl_proof> proof(new gl_proof());
-    std::vector<gl_t> h_apow_quot;          // source of an async upload: alive until the function returns (after the last sync)
+    std::vector<gl_t> h_apow_quot;          // sources of async uploads: alive until the function returns (after the last sync)
+    std::vector<const gl_t*> h_open_cols;
 
     // ---- 4. wires commitment (prover.rs:145-156) ----
     DevBuf d_wit(ctx);
@@ -669,19 +670,18 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     {
         GL_TRY(ctx->ensure_dev_small(1 << 20));
         gl_t* d_open = ctx->dev_small + 4096;
-        size_t off = 0;
         ctx->timing_begin("construct the opening set");
         // zeta^i and (g zeta)^i tabulated once per proof, shared by all polynomials
         DevBuf d_zpow(ctx); GL_TRY(d_zpow.alloc(4 * n * sizeof(gl_t)));
         gl_t* zp = d_zpow.as<gl_t>();
-        hipLaunchKernelGGL(k_ext_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, zeta.a, zeta.b, (uint32_t)n, zp, zp + n);
-        hipLaunchKernelGGL(k_ext_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gzeta.a, gzeta.b, (uint32_t)n, zp + 2 * n, zp + 3 * n);
-        for (int o = 0; o < 4; o++) {
-            hipLaunchKernelGGL(k_eval_with_powers, dim3((unsigned)oracles[o]->ncols), dim3(256), 0, st, oracles[o]->coeffs, (uint32_t)n, (uint64_t)n,
-                               zp, zp + n, d_open + 2 * off);
-            off += oracles[o]->ncols;
-        }
-        hipLaunchKernelGGL(k_eval_with_powers, dim3(2), dim3(256), 0, st, zs.b->coeffs, (uint32_t)n, (uint64_t)n, zp + 2 * n, zp + 3 * n, d_open + 2 * nopen);
+        hipLaunchKernelGGL(k_ext_powers2, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, st, zeta.a, zeta.b, gzeta.a, gzeta.b, (uint32_t)n, zp);
+        // one launch for all 257 openings: the list of coefficient columns goes up as a small pointer table
+        for (int o = 0; o < 4; o++) for (size_t c = 0; c < oracles[o]->ncols; c++) h_open_cols.push_back(oracles[o]->coeffs + c * n);
+        h_open_cols.push_back(zs.b->coeffs); h_open_cols.push_back(zs.b->coeffs + n);
+        DevBuf d_open_cols(ctx); GL_TRY(d_open_cols.alloc(h_open_cols.size() * sizeof(gl_t*)));
+        GL_TRY(h2d_async(ctx, d_open_cols.p, h_open_cols.data(), h_open_cols.size() * sizeof(gl_t*)));
+        hipLaunchKernelGGL(k_eval_list_with_powers, dim3((unsigned)h_open_cols.size()), dim3(256), 0, st, d_open_cols.as<const gl_t*>(), (uint32_t)n,
+                           (uint32_t)nopen, zp, zp + n, zp + 2 * n, zp + 3 * n, d_open);
         ctx->timing_end();
         GL_CHECK_HIP(hipGetLastError());
         std::vector<gl_t> tmp(2 * nopen + 4);
