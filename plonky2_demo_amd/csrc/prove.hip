@@ -198,6 +198,7 @@ static int partial_products_values(gl_ctx* ctx, const gl_circuit* cir, const gl_
     DevBuf d_chunk(ctx), d_rowp(ctx), d_seg(ctx);
     const uint32_t nseg = (uint32_t)((n + GLP_SEG - 1) / GLP_SEG);
     GL_TRY(d_chunk.alloc(2 * GLP_CHUNKS * n * sizeof(gl_t)));
+    DevBuf d_den(ctx); GL_TRY(d_den.alloc(2 * GLP_CHUNKS * n * sizeof(gl_t)));
     GL_TRY(d_rowp.alloc(2 * n * sizeof(gl_t)));
     GL_TRY(d_seg.alloc(2 * (size_t)nseg * sizeof(gl_t)));
     GlPowTable xt;
@@ -208,7 +209,8 @@ static int partial_products_values(gl_ctx* ctx, const gl_circuit* cir, const gl_
     for (int i = 0; i < 2; i++) { pp.betas[i] = gl_canon(betas[i]); pp.gammas[i] = gl_canon(gammas[i]); }
     pp.n = (uint32_t)n; pp.chunk_prod = d_chunk.as<gl_t>(); pp.row_prod = d_rowp.as<gl_t>();
     ctx->timing_begin("compute partial products");
-    hipLaunchKernelGGL(k_pp_chunk_products, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, st, pp);
+    hipLaunchKernelGGL(k_pp_chunk_terms, dim3((unsigned)((n + 255) / 256), 2 * GLP_CHUNKS), dim3(256), 0, st, pp, d_den.as<gl_t>());
+    hipLaunchKernelGGL(k_pp_chunk_products, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, st, pp, d_den.as<const gl_t>());
     hipLaunchKernelGGL(k_z_segment_products, dim3(nseg, 2), dim3(256), 0, st, d_rowp.as<gl_t>(), (uint32_t)n, d_seg.as<gl_t>());
     hipLaunchKernelGGL(k_z_segment_scan, dim3(1), dim3(64), 0, st, d_seg.as<gl_t>(), nseg);
     hipLaunchKernelGGL(k_z_finalize, dim3(nseg, 2), dim3(256), 0, st, d_rowp.as<gl_t>(), d_chunk.as<gl_t>(), d_seg.as<gl_t>(), (uint32_t)n, d_zs);

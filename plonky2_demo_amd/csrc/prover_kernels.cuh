@@ -35,49 +35,59 @@ __device__ __forceinline__ gl_t glp_pow2level(const gl_t* lo, const gl_t* hi, ui
     return gl_mul(lo[e & 2047], hi[e >> 11]);
 }
 
-// one thread per trace row: the 10 chunk products  prod_{j in chunk} (w_j + beta k_j x + gamma) / (w_j + beta sigma_j + gamma)
-__global__ __launch_bounds__(256) void k_pp_chunk_products(GlPermParams p) {
+// The 10 chunk products  prod_{j in chunk} (w_j + beta k_j x + gamma) / (w_j + beta sigma_j + gamma)  of every row, in two
+// launches so that the long dependent multiply chain is spread over 20 x more lanes:
+//   k_pp_chunk_terms     one thread per (row, challenge, chunk): numerator and denominator product of the chunk's 8 wires
+//                        (grid.y = 2 * 10); the numerator goes to chunk_prod, the denominator to den_prod
+//   k_pp_chunk_products  one thread per (row, challenge): ONE inversion for the 10 denominators (Montgomery), the quotients and
+//                        their product over the row
+__global__ __launch_bounds__(256) void k_pp_chunk_terms(GlPermParams p, gl_t* __restrict__ den_prod /* [2][10][n] */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
+    const int a = blockIdx.y / GLP_CHUNKS, c = blockIdx.y % GLP_CHUNKS;
     const gl_t x = glp_pow2level(p.xpow_lo, p.xpow_hi, i);
-    {
-        const int a = blockIdx.y;                       // one challenge per grid row: twice the waves, half the dependent chain
-        const gl_t beta = p.betas[a], gamma = p.gammas[a];
-        const gl_t bx = gl_mul(beta, x);
-        gl_t nump[GLP_CHUNKS], denp[GLP_CHUNKS];
+    const gl_t beta = p.betas[a], gamma = p.gammas[a];
+    const gl_t bx = gl_mul(beta, x);
+    gl_t np = 1, dp = 1;
 #pragma unroll
-        for (int c = 0; c < GLP_CHUNKS; c++) {
-            gl_t np = 1, dp = 1;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int j = c * 8 + q;
-                const gl_t w = p.wires[(size_t)j * p.n + i];
-                const gl_t s = p.sigmas[(size_t)j * p.n + i];
-                np = gl_mul(np, gl_add(gl_mul_add(w, bx, p.k_is[j]), gamma));
-                dp = gl_mul(dp, gl_add(gl_mul_add(w, beta, s), gamma));
-            }
-            nump[c] = np; denp[c] = dp;
-        }
-        // invert the 10 denominators with one inversion (Montgomery)
-        gl_t pre[GLP_CHUNKS];
-        gl_t acc = 1;
-#pragma unroll
-        for (int c = 0; c < GLP_CHUNKS; c++) { pre[c] = acc; acc = gl_mul(acc, denp[c]); }
-        gl_t inv = gl_inv(acc);
-        gl_t rowp = 1;
-#pragma unroll
-        for (int c = GLP_CHUNKS - 1; c >= 0; c--) {
-            gl_t dinv = gl_mul(inv, pre[c]);
-            inv = gl_mul(inv, denp[c]);
-            nump[c] = gl_mul(nump[c], dinv);
-        }
-#pragma unroll
-        for (int c = 0; c < GLP_CHUNKS; c++) {
-            p.chunk_prod[((size_t)a * GLP_CHUNKS + c) * p.n + i] = gl_canon(nump[c]);
-            rowp = gl_mul(rowp, nump[c]);
-        }
-        p.row_prod[(size_t)a * p.n + i] = gl_canon(rowp);
+    for (int q = 0; q < 8; q++) {
+        const int j = c * 8 + q;
+        const gl_t w = p.wires[(size_t)j * p.n + i];
+        const gl_t s = p.sigmas[(size_t)j * p.n + i];
+        np = gl_mul(np, gl_add(gl_mul_add(w, bx, p.k_is[j]), gamma));
+        dp = gl_mul(dp, gl_add(gl_mul_add(w, beta, s), gamma));
     }
+    p.chunk_prod[((size_t)a * GLP_CHUNKS + c) * p.n + i] = np;
+    den_prod[((size_t)a * GLP_CHUNKS + c) * p.n + i] = dp;
+}
+__global__ __launch_bounds__(256) void k_pp_chunk_products(GlPermParams p, const gl_t* __restrict__ den_prod) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    const int a = blockIdx.y;
+    gl_t nump[GLP_CHUNKS], denp[GLP_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < GLP_CHUNKS; c++) {
+        nump[c] = p.chunk_prod[((size_t)a * GLP_CHUNKS + c) * p.n + i];
+        denp[c] = den_prod[((size_t)a * GLP_CHUNKS + c) * p.n + i];
+    }
+    gl_t pre[GLP_CHUNKS];
+    gl_t acc = 1;
+#pragma unroll
+    for (int c = 0; c < GLP_CHUNKS; c++) { pre[c] = acc; acc = gl_mul(acc, denp[c]); }
+    gl_t inv = gl_inv(acc);
+    gl_t rowp = 1;
+#pragma unroll
+    for (int c = GLP_CHUNKS - 1; c >= 0; c--) {
+        gl_t dinv = gl_mul(inv, pre[c]);
+        inv = gl_mul(inv, denp[c]);
+        nump[c] = gl_mul(nump[c], dinv);
+    }
+#pragma unroll
+    for (int c = 0; c < GLP_CHUNKS; c++) {
+        p.chunk_prod[((size_t)a * GLP_CHUNKS + c) * p.n + i] = gl_canon(nump[c]);
+        rowp = gl_mul(rowp, nump[c]);
+    }
+    p.row_prod[(size_t)a * p.n + i] = gl_canon(rowp);
 }
 
 // ---- exclusive multiplicative scan of row_prod over rows: Z(x_i) = prod_{i' < i} P_i' -----------------------
