@@ -190,6 +190,13 @@ static int h2d_async(gl_ctx* c, void* dst, const void* src, size_t bytes) {
 // in C++.  Every phase leaves its polynomials in HBM and hands back only what the transcript needs.
 // ======================================================================================================================
 
+// the coset shifts of get_unique_coset_shifts (field/src/cosets.rs:9-24) are 1, 7, 7^2, ...: lets the kernels step beta x k_j by x7
+static uint32_t k_is_are_powers_of_7(const gl_circuit_desc& d) {
+    gl_t x = 1;
+    for (int j = 0; j < 80; j++) { if (gl_canon(d.k_is[j]) != x) return 0; x = gl_canon(gl_mul(x, GL_MULT_GENERATOR)); }
+    return 1;
+}
+
 // ---- 6. all_wires_permutation_partial_products (plonk/prover.rs:332-416): d_zs[20][n] VALUES ----
 static int partial_products_values(gl_ctx* ctx, const gl_circuit* cir, const gl_t* d_wires, const gl_t* betas, const gl_t* gammas, gl_t* d_zs) {
     const gl_circuit_desc& d = cir->desc;
@@ -206,6 +213,7 @@ static int partial_products_values(gl_ctx* ctx, const gl_circuit* cir, const gl_
     GlPermParams pp;
     pp.wires = d_wires; pp.sigmas = cir->d_sigmas; pp.xpow_lo = xt.lo; pp.xpow_hi = xt.hi;
     for (int j = 0; j < 80; j++) pp.k_is[j] = d.k_is[j];
+    pp.k_is_powers_of_7 = k_is_are_powers_of_7(d);
     for (int i = 0; i < 2; i++) { pp.betas[i] = gl_canon(betas[i]); pp.gammas[i] = gl_canon(gammas[i]); }
     pp.n = (uint32_t)n; pp.chunk_prod = d_chunk.as<gl_t>(); pp.row_prod = d_rowp.as<gl_t>();
     ctx->timing_begin("compute partial products");
@@ -254,6 +262,7 @@ static int quotient_chunks(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* w
     q.cs = cir->cs_batch->lde; q.wires = wires->lde; q.zs = zs->lde; q.xpow_lo = xt.lo; q.xpow_hi = xt.hi;
     q.alpha_pows = d_apow; q.out = d_q;
     for (int j = 0; j < 80; j++) q.k_is[j] = d.k_is[j];
+    q.k_is_powers_of_7 = k_is_are_powers_of_7(d);
     for (int i = 0; i < 2; i++) { q.betas[i] = gl_canon(betas[i]); q.gammas[i] = gl_canon(gammas[i]); }
     for (int i = 0; i < 4; i++) q.pi_hash[i] = gl_canon(pi_hash[i]);
     {   // ZeroPolyOnCoset (field/src/zero_poly_coset.rs:19-36)

@@ -27,6 +27,7 @@ struct GlPermParams {
     gl_t k_is[GLP_MAX_ROUTED];
     gl_t betas[2], gammas[2];
     uint32_t n;
+    uint32_t k_is_powers_of_7;  // k_is[j] = 7^j (get_unique_coset_shifts, field/src/cosets.rs:9-24): beta x k_j by a running x7
     gl_t* chunk_prod;           // [2][10][n]
     gl_t* row_prod;             // [2][n]
 };
@@ -49,13 +50,16 @@ __global__ __launch_bounds__(256) void k_pp_chunk_terms(GlPermParams p, gl_t* __
     const gl_t beta = p.betas[a], gamma = p.gammas[a];
     const gl_t bx = gl_mul(beta, x);
     gl_t np = 1, dp = 1;
+    gl_t bxk = gl_mul(bx, p.k_is[c * 8]);               // beta x k_j, advanced by x7 when the shifts are the usual 7^j
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const int j = c * 8 + q;
         const gl_t w = p.wires[(size_t)j * p.n + i];
         const gl_t s = p.sigmas[(size_t)j * p.n + i];
-        np = gl_mul(np, gl_add(gl_mul_add(w, bx, p.k_is[j]), gamma));
+        if (q && !p.k_is_powers_of_7) bxk = gl_mul(bx, p.k_is[j]);
+        np = gl_mul(np, gl_add(gl_add(w, bxk), gamma));
         dp = gl_mul(dp, gl_add(gl_mul_add(w, beta, s), gamma));
+        if (p.k_is_powers_of_7) bxk = gl_mul_small(bxk, 7);
     }
     p.chunk_prod[((size_t)a * GLP_CHUNKS + c) * p.n + i] = np;
     den_prod[((size_t)a * GLP_CHUNKS + c) * p.n + i] = dp;
@@ -161,6 +165,7 @@ struct GlQuotParams {
     gl_t zh_evals[8], zh_inv[8];    // Z_H on the coset by i mod 8 and inverses (field/src/zero_poly_coset.rs)
     gl_t n_field;                   // n as a field element
     uint32_t lgN, num_constants, num_selectors, num_gates, next_step;
+    uint32_t k_is_powers_of_7;
     uint8_t gate_types[8];
     uint32_t gate_sel[8], group_start[8], group_end[8];
 };
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     // partial-product checks (util/partial_products.rs:52-76): terms 2 + 10 a + c
     {
         gl_t bx0 = gl_mul(p.betas[0], x), bx1 = gl_mul(p.betas[1], x);
+        gl_t bxk0 = gl_mul(bx0, p.k_is[0]), bxk1 = gl_mul(bx1, p.k_is[0]);   // beta x k_j: a running x7 when k_j = 7^j
         gl_t prev0 = zs[0], prev1 = zs[N];
 #pragma unroll 1
         for (int c = 0; c < GLP_CHUNKS; c++) {
@@ -280,11 +286,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const int j = c * 8 + q;
-                const gl_t wv = w[(size_t)j * N], sg = cs[(size_t)(p.num_constants + j) * N], k = p.k_is[j];
-                n0 = gl_mul(n0, gl_add(gl_mul_add(wv, bx0, k), p.gammas[0]));
+                const gl_t wv = w[(size_t)j * N], sg = cs[(size_t)(p.num_constants + j) * N];
+                if (!p.k_is_powers_of_7) { const gl_t k = p.k_is[j]; bxk0 = gl_mul(bx0, k); bxk1 = gl_mul(bx1, k); }
+                n0 = gl_mul(n0, gl_add(gl_add(wv, bxk0), p.gammas[0]));
                 d0 = gl_mul(d0, gl_add(gl_mul_add(wv, p.betas[0], sg), p.gammas[0]));
-                n1 = gl_mul(n1, gl_add(gl_mul_add(wv, bx1, k), p.gammas[1]));
+                n1 = gl_mul(n1, gl_add(gl_add(wv, bxk1), p.gammas[1]));
                 d1 = gl_mul(d1, gl_add(gl_mul_add(wv, p.betas[1], sg), p.gammas[1]));
+                if (p.k_is_powers_of_7) { bxk0 = gl_mul_small(bxk0, 7); bxk1 = gl_mul_small(bxk1, 7); }
             }
             const gl_t next0 = (c == GLP_CHUNKS - 1) ? p.zs[i_next] : zs[(size_t)(2 + c) * N];
             const gl_t next1 = (c == GLP_CHUNKS - 1) ? p.zs[N + i_next] : zs[(size_t)(2 + (GLP_CHUNKS - 1) + c) * N];
