@@ -16,6 +16,7 @@ struct gl_circuit {
     size_t n = 0;
     gl_batch* cs_batch = nullptr;     // constants || sigmas commitment
     gl_t* d_sigmas = nullptr;         // sigma VALUES [80][n]
+    gl_t* d_l0_coset = nullptr;       // L_0 on the LDE coset [8n]
     gl_t circuit_digest[4];
 };
 
@@ -119,6 +120,7 @@ extern "C" void gl_circuit_free(gl_circuit* c) {
     if (!c) return;
     if (c->cs_batch) gl_batch_free(c->cs_batch);
     if (c->d_sigmas) c->ctx->pool_release(c->d_sigmas);
+    if (c->d_l0_coset) c->ctx->pool_release(c->d_l0_coset);
     delete c;
 }
 
@@ -134,6 +136,22 @@ extern "C" int gl_circuit_create(gl_ctx* ctx, const gl_circuit_desc* desc, const
     GL_TRY(gl_batch_from_values(ctx, cols.data(), ncs, n, desc->rate_bits, 0, desc->cap_height, &c->cs_batch));   // circuit_builder.rs:1020-1028
     GL_TRY(ctx->pool_alloc(80 * n * sizeof(gl_t), (void**)&c->d_sigmas));
     GL_TRY(gl_copy_h2d(ctx, c->d_sigmas, h_cs + (size_t)desc->num_constants * n, 80 * n * sizeof(gl_t)));
+    {   // L_0 on the coset 7 H_N, N = n << rate_bits
+        const uint32_t lgN = desc->degree_bits + desc->rate_bits;
+        const size_t N = size_t(1) << lgN;
+        GL_TRY(ctx->pool_alloc(N * sizeof(gl_t), (void**)&c->d_l0_coset));
+        GlPowTable xt;
+        GL_TRY(ctx->get_pow_table(gl_host_root_of_unity(lgN), GL_MULT_GENERATOR, (uint32_t)((N + 2047) >> 11), &xt));
+        gl_t zh[8];
+        gl_t g_pow_n = GL_MULT_GENERATOR; for (uint32_t i = 0; i < desc->degree_bits; i++) g_pow_n = gl_sqr(g_pow_n);
+        gl_t w8 = gl_host_root_of_unity(desc->rate_bits), x = 1;
+        for (int i = 0; i < 8; i++) { zh[i] = gl_canon(gl_sub(gl_mul(g_pow_n, x), 1)); x = gl_mul(x, w8); }
+        GL_TRY(ctx->ensure_dev_small(1 << 20));
+        GL_TRY(gl_copy_h2d(ctx, ctx->dev_small, zh, sizeof zh));
+        hipLaunchKernelGGL(k_l0_on_coset, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, xt.lo, xt.hi, (uint32_t)N, (gl_t)n, ctx->dev_small, c->d_l0_coset);
+        GL_CHECK_HIP(hipGetLastError());
+        GL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
     // circuit_digest = hash_no_pad(cap || hash_pad([]) || [degree_bits])   (circuit_builder.rs:1089-1100)
     std::vector<gl_t> parts((size_t(4) << desc->cap_height));
     GL_TRY(gl_batch_cap(c->cs_batch, parts.data()));
@@ -270,6 +288,7 @@ static int quotient_chunks(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* w
         gl_t w8 = gl_host_root_of_unity(d.rate_bits), x = 1;
         for (int i = 0; i < 8; i++) { q.zh_evals[i] = gl_canon(gl_sub(gl_mul(g_pow_n, x), 1)); q.zh_inv[i] = gl_canon(gl_inv(q.zh_evals[i])); x = gl_mul(x, w8); }
     }
+    q.l0_coset = cir->d_l0_coset;
     q.n_field = (gl_t)n; q.lgN = lgN; q.num_constants = d.num_constants; q.num_selectors = d.num_selectors; q.num_gates = d.num_gates;
     q.next_step = 1u << d.rate_bits;
     for (unsigned g = 0; g < d.num_gates; g++) { q.gate_types[g] = d.gate_types[g]; q.gate_sel[g] = d.gate_selector_index[g]; q.group_start[g] = d.gate_group_start[g]; q.group_end[g] = d.gate_group_end[g]; }

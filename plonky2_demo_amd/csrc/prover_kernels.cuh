@@ -164,6 +164,7 @@ struct GlQuotParams {
     gl_t pi_hash[4];
     gl_t zh_evals[8], zh_inv[8];    // Z_H on the coset by i mod 8 and inverses (field/src/zero_poly_coset.rs)
     gl_t n_field;                   // n as a field element
+    const gl_t* l0_coset;           // L_0 on the coset: l0_coset[i] = Z_H(x_i) / (n (x_i - 1)), x_i = 7 w_N^i (built with the circuit)
     uint32_t lgN, num_constants, num_selectors, num_gates, next_step;
     uint32_t k_is_powers_of_7;
     uint8_t gate_types[8];
@@ -255,6 +256,15 @@ __device__ __forceinline__ void glq_poseidon_gate(const gl_t* __restrict__ w, si
     for (int i = 0; i < 12; i++) { acc.add(t++, gl_sub(s[i], *wp)); wp = glq_step(wp, N); }
 }
 
+// L_0(x) = Z_H(x) / (n (x - 1)) on the N coset points (plonk_common.rs:61-71, zero_poly_coset.rs:55-60): one field inversion per
+// point, so it is tabulated once per circuit instead of being recomputed (96 multiplies) by every proof at every point
+__global__ __launch_bounds__(256) void k_l0_on_coset(const gl_t* xpow_lo, const gl_t* xpow_hi, uint32_t N, gl_t n_field, const gl_t* zh_evals8, gl_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const gl_t x = glp_pow2level(xpow_lo, xpow_hi, i);
+    out[i] = gl_canon(gl_mul(zh_evals8[i & 7], gl_inv(gl_mul(n_field, gl_sub(x, 1)))));
+}
+
 // The vanishing combination is a sum over terms, so it is evaluated by two launches with very different register needs
 // (the PoseidonGate re-runs a permutation; everything else streams wires): POSEIDON_PART = false writes every term except
 // the PoseidonGate's, POSEIDON_PART = true adds the PoseidonGate's filtered constraint sum to it.
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     const gl_t x = glp_pow2level(p.xpow_lo, p.xpow_hi, i);          // 7 * w^i
     const uint32_t i_next = (i + p.next_step) & (uint32_t)(N - 1);
     // L_0(x) (Z(x) - 1)            (vanishing_poly.rs:263-268; zero_poly_coset.rs:55-60)
-    const gl_t l0 = gl_mul(p.zh_evals[i & 7], gl_inv(gl_mul(p.n_field, gl_sub(x, 1))));
+    const gl_t l0 = p.l0_coset[i];
     total.add(0, gl_mul(l0, gl_sub(zs[0], 1)));
     total.add(1, gl_mul(l0, gl_sub(zs[N], 1)));
     // partial-product checks (util/partial_products.rs:52-76): terms 2 + 10 a + c
