@@ -265,6 +265,18 @@ int gl_prove_device(gl_ctx* ctx, const gl_circuit* c, const uint64_t* d_wires, c
  * generator's sponge produces it as a by-product, and hashing 3 m^2 inputs is a sequential host job */
 int gl_prove_device_hashed(gl_ctx* ctx, const gl_circuit* c, const uint64_t* d_wires, const uint64_t* h_public_inputs,
                            size_t num_public_inputs, const uint64_t public_inputs_hash[4], gl_proof** out);
+/* Many independent proofs in flight on one GPU from one call -- what the reference gets from its Rayon pool when a batch of
+ * witnesses is proved.  The pool owns one device-resident circuit and `lanes` contexts (HIP stream, allocator, witness
+ * generator each); item i is proved on lane i % lanes by `lanes` host threads inside the call.  `hc` is borrowed. */
+typedef struct gl_prover_pool gl_prover_pool;
+int gl_prover_pool_create(int device, const gl_host_circuit* hc, uint32_t lanes, gl_prover_pool** out);
+uint32_t gl_prover_pool_lanes(const gl_prover_pool* p);
+const gl_circuit* gl_prover_pool_circuit(const gl_prover_pool* p);     /* for gl_circuit_digest / _constants_sigmas_cap */
+/* a[i], b[i]: row-major m x m operands on the host; filler_seeds may be null (seed i); out_proofs[count] */
+int gl_prover_pool_prove_matmul(gl_prover_pool* p, size_t count, const uint64_t* const* a, const uint64_t* const* b,
+                                const uint64_t* filler_seeds, gl_proof** out_proofs);
+void gl_prover_pool_free(gl_prover_pool* p);
+
 /* ProofWithPublicInputs::to_bytes (plonk/proof.rs:104-110; util/serialization/mod.rs:1939-1981) */
 size_t gl_proof_num_bytes(const gl_proof* p);
 int gl_proof_bytes(const gl_proof* p, uint8_t* h_out, size_t cap);

@@ -8,6 +8,6 @@ Names and argument meaning follow the reference so that the parity tests read li
 from ._lib import LIB_PATH, Plonky2Mi355xError  # noqa: F401
 from . import api  # noqa: F401
 from .api import (  # noqa: F401
-    Challenger, CircuitData, Context, FriProver, GenericCircuitData, MatmulCircuit, MerkleTree, PolynomialBatch, Proof, coset_fft, coset_ifft, default_context, fft, hash_or_noop, ifft,
+    Challenger, CircuitData, Context, FriProver, GenericCircuitData, MatmulCircuit, MerkleTree, PolynomialBatch, Proof, ProverPool, coset_fft, coset_ifft, default_context, fft, hash_or_noop, ifft,
     lde_onto_coset, poseidon, pow_grind, GOLDILOCKS_ORDER, COSET_SHIFT,
 )

@@ -114,6 +114,11 @@ SIGNATURES = {
     "gl_prove": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "gl_prove_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "gl_prove_device_hashed": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, ctypes.POINTER(c_vp)]),
+    "gl_prover_pool_create": (c_int, [c_int, c_vp, c_u32, ctypes.POINTER(c_vp)]),
+    "gl_prover_pool_lanes": (c_u32, [c_vp]),
+    "gl_prover_pool_circuit": (c_vp, [c_vp]),
+    "gl_prover_pool_prove_matmul": (c_int, [c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
+    "gl_prover_pool_free": (None, [c_vp]),
     "gl_proof_num_bytes": (c_sz, [c_vp]),
     "gl_proof_bytes": (c_int, [c_vp, c_vp, c_sz]),
     "gl_proof_challenges": (c_sz, [c_vp, c_vp]),

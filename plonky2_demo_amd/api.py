@@ -603,6 +603,36 @@ class GenericCircuitData:
             pass
 
 
+class ProverPool:
+    """Many proofs in flight on one GPU from one call (gl_prover_pool_*): one circuit, `lanes` streams and host threads in C++."""
+
+    def __init__(self, host, lanes=4, device=0):
+        self.host = host
+        h = ctypes.c_void_p()
+        check(lib.gl_prover_pool_create(device, host.handle, lanes, ctypes.byref(h)))
+        self.handle = h.value
+
+    def prove_matmul(self, operands, filler_seeds=None):
+        """operands: list of (a, b) m x m arrays; returns the list of Proof objects in the same order."""
+        m2 = self.host.m ** 2
+        aa = [np.ascontiguousarray(_u64(a).reshape(-1)) for a, _ in operands]
+        bb = [np.ascontiguousarray(_u64(b).reshape(-1)) for _, b in operands]
+        if any(x.size != m2 for x in aa + bb):
+            raise ValueError("operands must be m x m")
+        k = len(operands)
+        pa = (ctypes.c_void_p * k)(*[x.ctypes.data for x in aa])
+        pb = (ctypes.c_void_p * k)(*[x.ctypes.data for x in bb])
+        seeds = None if filler_seeds is None else np.ascontiguousarray(np.asarray(filler_seeds, dtype=np.uint64))
+        out = (ctypes.c_void_p * k)()
+        check(lib.gl_prover_pool_prove_matmul(self.handle, k, pa, pb, _p(seeds) if seeds is not None else None, out))
+        return [Proof(out[i], self.host.n) for i in range(k)]
+
+    def close(self):
+        if self.handle:
+            lib.gl_prover_pool_free(self.handle)
+            self.handle = None
+
+
 class CircuitView:
     """The same device-resident CircuitData used from another context (stream) of the same device."""
 

@@ -147,3 +147,89 @@ extern "C" int gl_matmul_witgen_run(gl_matmul_witgen* g, const uint64_t* a, cons
     GL_CHECK_HIP(hipStreamSynchronize(st));                // the pinned staging buffers are reused by the next call
     return GL_OK;
 }
+
+// ======================================================================================================================
+// Prover pool: many independent proofs in flight on one GPU from ONE call -- the C++ counterpart of the reference fanning a
+// batch out over its Rayon pool.  A pool owns one device-resident circuit and `lanes` contexts (HIP stream + allocator +
+// witness generator each); gl_prover_pool_prove_matmul hands item i to lane i % lanes on `lanes` host threads, so that the
+// transcript round trips and the host-side hash sponge of one proof hide behind the kernels of the others.
+// ======================================================================================================================
+#include <thread>
+#include <atomic>
+
+struct gl_prover_pool {
+    int device = 0;
+    const gl_host_circuit* hc = nullptr;                 // borrowed
+    std::vector<gl_ctx*> ctxs;
+    gl_circuit* circuit = nullptr;                       // owned by ctxs[0]
+    std::vector<gl_matmul_witgen*> gens;
+    std::vector<uint64_t*> d_wires;                      // one witness matrix per lane
+};
+
+extern "C" void gl_prover_pool_free(gl_prover_pool* p) {
+    if (!p) return;
+    for (size_t k = 0; k < p->ctxs.size(); k++) {
+        if (k < p->gens.size() && p->gens[k]) gl_matmul_witgen_free(p->gens[k]);
+        if (k < p->d_wires.size() && p->d_wires[k]) (void)gl_dev_free(p->ctxs[k], p->d_wires[k]);
+    }
+    if (p->circuit) gl_circuit_free(p->circuit);
+    for (gl_ctx* c : p->ctxs) gl_ctx_destroy(c);
+    delete p;
+}
+
+extern "C" int gl_prover_pool_create(int device, const gl_host_circuit* hc, uint32_t lanes, gl_prover_pool** out) {
+    GL_REQUIRE(hc && out && lanes >= 1 && lanes <= 64, GL_ERR_ARG, "gl_prover_pool_create: bad argument (1..64 lanes)");
+    std::unique_ptr<gl_prover_pool, void (*)(gl_prover_pool*)> p(new gl_prover_pool(), gl_prover_pool_free);
+    p->device = device; p->hc = hc;
+    const size_t n = hc->hc.n;
+    for (uint32_t k = 0; k < lanes; k++) {
+        gl_ctx* c = nullptr;
+        GL_TRY(gl_ctx_create(device, nullptr, &c));
+        p->ctxs.push_back(c);
+    }
+    GL_TRY(gl_circuit_from_host(p->ctxs[0], hc, &p->circuit));
+    p->gens.assign(lanes, nullptr); p->d_wires.assign(lanes, nullptr);
+    for (uint32_t k = 0; k < lanes; k++) {
+        GL_TRY(gl_matmul_witgen_create(p->ctxs[k], hc, &p->gens[k]));
+        void* d = nullptr;
+        GL_TRY(gl_dev_alloc(p->ctxs[k], 135 * n * sizeof(uint64_t), &d));
+        p->d_wires[k] = (uint64_t*)d;
+    }
+    *out = p.release();
+    return GL_OK;
+}
+
+extern "C" uint32_t gl_prover_pool_lanes(const gl_prover_pool* p) { return p ? (uint32_t)p->ctxs.size() : 0; }
+extern "C" const gl_circuit* gl_prover_pool_circuit(const gl_prover_pool* p) { return p ? p->circuit : nullptr; }
+
+// count proofs of A_i * B_i = C_i: a[i], b[i] row-major m x m operands on the host, filler_seeds[i] as gl_matmul_witness.
+// out_proofs[i] receives a gl_proof (gl_proof_free each); the public inputs are inside the proof bytes.  Returns the first
+// error of any lane (proofs already produced stay valid, the others are null).
+extern "C" int gl_prover_pool_prove_matmul(gl_prover_pool* p, size_t count, const uint64_t* const* a, const uint64_t* const* b,
+                                           const uint64_t* filler_seeds, gl_proof** out_proofs) {
+    GL_REQUIRE(p && (count == 0 || (a && b && out_proofs)), GL_ERR_ARG, "gl_prover_pool_prove_matmul: null argument");
+    for (size_t i = 0; i < count; i++) out_proofs[i] = nullptr;
+    const size_t lanes = p->ctxs.size(), npis = 3 * p->hc->hc.m * p->hc->hc.m;
+    std::atomic<int> first_error{GL_OK};
+    std::vector<std::string> messages(lanes);
+    auto work = [&](size_t lane) {
+        std::vector<uint64_t> pis(npis);
+        uint64_t pi_hash[4];
+        for (size_t i = lane; i < count && first_error.load() == GL_OK; i += lanes) {
+            int st = (a[i] && b[i]) ? GL_OK : GL_ERR_ARG;
+            if (st == GL_OK) st = gl_matmul_witgen_run(p->gens[lane], a[i], b[i], filler_seeds ? filler_seeds[i] : (uint64_t)i, p->d_wires[lane], pis.data(), pi_hash);
+            if (st == GL_OK) st = gl_prove_device_hashed(p->ctxs[lane], p->circuit, p->d_wires[lane], pis.data(), npis, pi_hash, &out_proofs[i]);
+            if (st != GL_OK) { int expected = GL_OK; messages[lane] = gl_last_error(); first_error.compare_exchange_strong(expected, st); }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (size_t k = 1; k < lanes && k < count; k++) threads.emplace_back(work, k);
+    work(0);
+    for (auto& t : threads) t.join();
+    const int st = first_error.load();
+    if (st != GL_OK) {
+        for (auto& m : messages) if (!m.empty()) return gl_fail(st, m.c_str(), __FILE__, __LINE__);
+        return gl_fail(st, "gl_prover_pool_prove_matmul: a lane failed", __FILE__, __LINE__);
+    }
+    return GL_OK;
+}

@@ -658,3 +658,28 @@ def test_generic_circuits_over_the_same_gate_set(gpu, orc, kind, param):
     assert gp.to_bytes() == op.to_bytes()
     assert cd.verify(gp) == (True, "")
     assert oc.verify_bytes(gp.to_bytes(), cd.constants_sigmas_cap, cd.circuit_digest)[0]
+
+
+def test_prover_pool_matches_individual_proofs(gpu):
+    # gl_prover_pool_*: one call, several proofs in flight on C++ threads (witness generation in HBM + prove per lane); every
+    # proof equals the one produced alone on the default context, whatever lane and order it ran in
+    p, ctx = gpu
+    m = 20
+    hc = p.MatmulCircuit(m)
+    cd = hc.build()
+    ops, seeds, want = [], [], []
+    for k in range(11):
+        a, b = rand_field(2000 + k, m * m) % (2**32 - 1), rand_field(2100 + k, m * m) % (2**32 - 1)
+        ops.append((a, b)); seeds.append(50 + k)
+        wires, pis = hc.witness(a, b, filler_seed=50 + k)
+        want.append(cd.prove(wires, pis).to_bytes())
+    pool = p.ProverPool(hc, lanes=3)
+    try:
+        for _ in range(2):
+            got = pool.prove_matmul(ops, seeds)
+            assert [g.to_bytes() for g in got] == want
+        assert pool.prove_matmul([]) == []
+        with pytest.raises(ValueError):
+            pool.prove_matmul([(ops[0][0][:5], ops[0][1])])
+    finally:
+        pool.close()

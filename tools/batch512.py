@@ -65,3 +65,14 @@ def run(kind):
 
 run("device")
 run("host")
+
+# the same batch through the C++ prover pool (gl_prover_pool_prove_matmul): threads, streams and witness generation inside the library
+pool = p.ProverPool(hc, lanes=nl)
+pool.prove_matmul(ops[:nl], list(range(nl)))
+t0 = time.perf_counter()
+proofs = pool.prove_matmul(ops, list(range(nproofs)))
+sizes = [len(pr.to_bytes()) for pr in proofs]
+dt = time.perf_counter() - t0
+print("config 4, 1 GPU, C++ prover pool: %d proofs in %.3f s = %.1f proofs/s (%.2f ms/proof), %d lanes, %.1f MB of proofs gathered"
+      % (nproofs, dt, nproofs / dt, dt / nproofs * 1e3, nl, sum(sizes) / 1e6), flush=True)
+pool.close()
