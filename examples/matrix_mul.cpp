@@ -1,8 +1,9 @@
 // The reference's demo program (plonky2/src/bin/matrix_mul.rs, examples/matrix_multiplication.rs) on the MI355X
 // backend: "I know A * B = C" for random m x m matrices of u32 entries -- build, prove, print, verify.
 //
-//   matrix_mul [m = 20] [seed]        (without a seed the operands come from std::random_device, as the
-//                                      reference draws them from ChaChaRng::from_entropy(), matrix_mul.rs:72-80)
+//   matrix_mul [m = 20] [seed] [batch]  (seed 0 / absent: operands from std::random_device, as the reference draws them
+//                                        from ChaChaRng::from_entropy(), matrix_mul.rs:72-80; batch > 1: that many
+//                                        independent proofs through gl_prover_pool, four in flight, each verified)
 //
 // Plain C++ over the C ABI of include/plonky2_mi355x.h; the only GPU-specific line is gl_ctx_create.
 #include <chrono>
@@ -24,7 +25,9 @@ static double ms_since(std::chrono::steady_clock::time_point t0) {
 
 int main(int argc, char** argv) {
     const size_t m = argc > 1 ? (size_t)atoi(argv[1]) : 20;                      // matrix_mul.rs:30
-    std::mt19937_64 rng(argc > 2 ? (uint64_t)strtoull(argv[2], nullptr, 10) : ((uint64_t)std::random_device{}() << 32) ^ std::random_device{}());
+    const uint64_t seed_arg = argc > 2 ? (uint64_t)strtoull(argv[2], nullptr, 10) : 0;
+    std::mt19937_64 rng(seed_arg ? seed_arg : ((uint64_t)std::random_device{}() << 32) ^ std::random_device{}());
+    const size_t batch = argc > 3 ? (size_t)atoi(argv[3]) : 1;
 
     // ---- build (matrix_mul.rs:25-67): circuit description on the host, constants/sigmas commitment on the GPU ----
     auto t0 = std::chrono::steady_clock::now();
@@ -69,6 +72,32 @@ int main(int argc, char** argv) {
     t0 = std::chrono::steady_clock::now();
     int st = gl_verify(&desc, cap.data(), digest.data(), bytes.data(), bytes.size());
     fprintf(stderr, "verify: %.1f ms: %s\n", ms_since(t0), st == GL_OK ? "accepted" : gl_last_error());
+
+    // ---- optional: a batch of independent proofs, several in flight (what a Rayon pool does for the reference) ----
+    if (st == GL_OK && batch > 1) {
+        gl_prover_pool* pool = nullptr;
+        CHECK(gl_prover_pool_create(0, hc, 4, &pool));
+        std::vector<std::vector<uint64_t>> as(batch, std::vector<uint64_t>(m * m)), bs(batch, std::vector<uint64_t>(m * m));
+        std::vector<const uint64_t*> pa(batch), pb(batch);
+        for (size_t i = 0; i < batch; i++) {
+            for (auto& x : as[i]) x = u32(rng);
+            for (auto& x : bs[i]) x = u32(rng);
+            pa[i] = as[i].data(); pb[i] = bs[i].data();
+        }
+        std::vector<gl_proof*> proofs(batch, nullptr);
+        t0 = std::chrono::steady_clock::now();
+        CHECK(gl_prover_pool_prove_matmul(pool, batch, pa.data(), pb.data(), nullptr, proofs.data()));
+        const double ms = ms_since(t0);
+        fprintf(stderr, "batch: %zu proofs in %.1f ms = %.1f proofs/s (witness generation included)\n", batch, ms, batch * 1e3 / ms);
+        for (size_t i = 0; i < batch && st == GL_OK; i++) {
+            std::vector<uint8_t> by(gl_proof_num_bytes(proofs[i]));
+            CHECK(gl_proof_bytes(proofs[i], by.data(), by.size()));
+            st = gl_verify(&desc, cap.data(), digest.data(), by.data(), by.size());
+        }
+        fprintf(stderr, "batch verify: %s\n", st == GL_OK ? "all accepted" : gl_last_error());
+        for (auto* pr : proofs) gl_proof_free(pr);
+        gl_prover_pool_free(pool);
+    }
 
     gl_proof_free(proof);
     gl_matmul_witgen_free(gen);

@@ -556,6 +556,8 @@ def test_demo_binary_builds_proves_and_verifies(gpu):
         assert r.returncode == 0, r.stderr
         assert r.stdout.strip() == "length of proof.public_inputs is %d" % (3 * m * m)      # matrix_mul.rs:90
         assert "accepted" in r.stderr
+    r = subprocess.run([exe, "20", "5", "9"], capture_output=True, text=True, timeout=300)   # + a batch of 9 through the pool
+    assert r.returncode == 0 and "all accepted" in r.stderr, r.stderr
 
 
 def test_concurrent_proofs_on_shared_circuit_are_deterministic(gpu):
