@@ -258,6 +258,10 @@ void gl_challenger_free(gl_challenger* c);
  * Returns GL_ERR_ZETA_IN_SUBGROUP for prover.rs:280-283. */
 int gl_prove(gl_ctx* ctx, const gl_circuit* c, const uint64_t* h_wires, const uint64_t* h_public_inputs,
              size_t num_public_inputs, gl_proof** out);
+/* same with the witness as the reference stores it, one host vector per wire: h_wire_columns[num_wires] -> n values each
+ * (`MatrixWitness.wire_values: Vec<Vec<F>>`), so that the caller does not have to flatten 135 vectors first */
+int gl_prove_columns(gl_ctx* ctx, const gl_circuit* c, const uint64_t* const* h_wire_columns,
+                     const uint64_t* h_public_inputs, size_t num_public_inputs, gl_proof** out);
 /* same with the witness matrix already resident in HBM (d_wires[num_wires][n]) */
 int gl_prove_device(gl_ctx* ctx, const gl_circuit* c, const uint64_t* d_wires, const uint64_t* h_public_inputs,
                     size_t num_public_inputs, gl_proof** out);

@@ -112,6 +112,7 @@ SIGNATURES = {
     "gl_challenger_state": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(c_u32)]),
     "gl_challenger_free": (None, [c_vp]),
     "gl_prove": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
+    "gl_prove_columns": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "gl_prove_device": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, ctypes.POINTER(c_vp)]),
     "gl_prove_device_hashed": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, ctypes.POINTER(c_vp)]),
     "gl_prover_pool_create": (c_int, [c_int, c_vp, c_u32, ctypes.POINTER(c_vp)]),

@@ -534,6 +534,17 @@ class CircuitData:
         check(lib.gl_prove(self.ctx.handle, self.handle, _p(wires), _p(pis), pis.size, ctypes.byref(h)))
         return Proof(h.value, self.host.n)
 
+    def prove_columns(self, columns, public_inputs):
+        """prove() from one host array per wire, as the reference keeps MatrixWitness.wire_values."""
+        cols = [np.ascontiguousarray(_u64(c)) for c in columns]
+        if len(cols) != 135 or any(c.size != self.host.n for c in cols):
+            raise ValueError("need 135 columns of n values")
+        pis = _u64(public_inputs)
+        ptrs = (ctypes.c_void_p * 135)(*[c.ctypes.data for c in cols])
+        h = ctypes.c_void_p()
+        check(lib.gl_prove_columns(self.ctx.handle, self.handle, ptrs, _p(pis), pis.size, ctypes.byref(h)))
+        return Proof(h.value, self.host.n)
+
     def prove_device(self, d_wires_ptr, public_inputs, public_inputs_hash=None):
         """prove() with the witness matrix already in HBM (raw device pointer to [135][n] u64)."""
         return _prove_device(self.ctx, self.handle, self.host.n, d_wires_ptr, public_inputs, public_inputs_hash)

@@ -609,6 +609,21 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
 extern "C" int gl_prove(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, const uint64_t* h_pis, size_t npis, gl_proof** out) {
     return prove_impl(ctx, cir, h_wires, false, h_pis, npis, nullptr, out);
 }
+// the witness as the reference holds it: one host vector per wire (MatrixWitness.wire_values: Vec<Vec<F>>, iop/witness.rs:256-258)
+extern "C" int gl_prove_columns(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* const* h_wire_columns, const uint64_t* h_pis, size_t npis, gl_proof** out) {
+    GL_REQUIRE(ctx && cir && h_wire_columns && out, GL_ERR_ARG, "gl_prove_columns: null argument");
+    GL_TRY(ctx->activate());
+    const size_t n = cir->n;
+    DevBuf d_wit(ctx); GL_TRY(d_wit.alloc(135 * n * sizeof(gl_t)));
+    ctx->timing_begin("H2D witness");
+    for (size_t c = 0; c < 135; c++) {
+        GL_REQUIRE(h_wire_columns[c], GL_ERR_ARG, "gl_prove_columns: null column");
+        GL_CHECK_HIP(hipMemcpyAsync(d_wit.as<gl_t>() + c * n, h_wire_columns[c], n * sizeof(gl_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->timing_end();
+    // pageable sources are staged by the runtime before each call returns; the proof is finished before d_wit is released
+    return prove_impl(ctx, cir, d_wit.as<uint64_t>(), true, h_pis, npis, nullptr, out);
+}
 extern "C" int gl_prove_device(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t* h_pis, size_t npis, gl_proof** out) {
     return prove_impl(ctx, cir, d_wires, true, h_pis, npis, nullptr, out);
 }

@@ -339,6 +339,9 @@ def test_prove_readme_instance(gpu, orc):
     assert proof.to_bytes() == op.to_bytes() and len(proof.to_bytes()) == 70288
     with pytest.raises(p.Plonky2Mi355xError):
         hc.build().prove(wires, pis[:-1])      # wrong number of public inputs
+    # the witness as 135 separate host vectors (MatrixWitness.wire_values)
+    cols = [wires[c].copy() for c in range(135)]
+    assert hc.build().prove_columns(cols, pis).to_bytes() == op.to_bytes()
 
 
 def test_prove_m64_matches_oracle(gpu, orc):
