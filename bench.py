@@ -238,7 +238,7 @@ def main():
         # secondary figure (not `value`): the same loop with witness generation inside the clock -- operands on the host,
         # arithmetic rows filled by the GPU, the sequential public-input hash sponge by the lane's host thread
         e2e = None
-        if args.e2e_steps > 0:
+        if args.e2e_steps > 0 and world == 1:                # single-GPU runs only: the scaling runs measure `value`
             # the host part of witness generation (several ms of sequential Poseidon per proof) is hidden by keeping three times
             # as many proofs in flight: while one lane's host thread hashes, the GPU works on the other lanes' proofs
             nl = args.e2e_lanes if args.e2e_lanes > 0 else 3 * nstreams
