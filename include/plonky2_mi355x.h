@@ -21,6 +21,14 @@
  *    merkle_tree.rs:137-143, fft.rs:175-181); here they are GL_ERR_ARG.
  *  - A gl_ctx is bound to one device and one HIP stream; calls on one ctx are issued in order on that
  *    stream.  Different ctxs may be used concurrently from different threads.
+ *  - Lifetime: every handle created on a context (gl_batch, gl_merkle, gl_circuit, gl_fri, gl_matmul_witgen) holds a
+ *    reference to it.  gl_ctx_destroy() drops the creator's reference: after it the gl_ctx pointer must not be passed to
+ *    any entry point again, but handles created earlier stay valid (they keep the stream, tables and allocator alive)
+ *    and may be used and freed afterwards IN ANY ORDER; the context is torn down when the last of them is freed.  A
+ *    binding may therefore give every handle a plain destructor (Rust `Drop`) without ordering them.  A gl_batch passed
+ *    to gl_fri_combine, and the gl_host_circuit passed to gl_matmul_witgen_create / gl_prover_pool_create, are
+ *    borrowed and must outlive the borrower.  Memory from gl_dev_alloc is not tied to the context (gl_dev_free accepts a
+ *    null ctx).
  *  - There is NO CPU fallback: without a HIP device every compute entry point fails with GL_ERR_HIP.
  */
 #ifndef PLONKY2_MI355X_H
@@ -76,6 +84,7 @@ typedef struct gl_circuit_desc {
 /* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL to let
  * the context create its own non-blocking stream. */
 int gl_ctx_create(int device, void* stream, gl_ctx** out);
+/* drops the creator's reference (see "Lifetime" above); synchronises the stream first */
 void gl_ctx_destroy(gl_ctx* ctx);
 int gl_ctx_synchronize(gl_ctx* ctx);
 /* scratch used between the two NTT passes (elements); default 2^24 (128 MiB). */

@@ -6,10 +6,10 @@
 //   plonky2/src/hash/hashing.rs:98-146 (compress, hash_n_to_m_no_pad: overwrite-mode sponge)
 //   plonky2/src/plonk/config.rs:55-66 (hash_or_noop)
 //   plonky2/src/hash/merkle_tree.rs:69-207, merkle_proofs.rs:54-75 (tree, cap, prove, verify)
-// Constant tables: plonky2_demo_amd/csrc/poseidon_constants.h (generated, KAT-validated).
+// Constant tables: gl_poseidon_tables.hpp, the oracle's OWN copy transcribed from reference-held data (oracle/make_tables.py).
 #pragma once
 #include "gl_field.hpp"
-#include "../plonky2_demo_amd/csrc/poseidon_constants.h"
+#include "gl_poseidon_tables.hpp"
 #include <array>
 #include <cstring>
 

@@ -52,7 +52,7 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr:
-            check(lib.gl_dev_free(self.ctx.handle, self.ptr))
+            check(lib.gl_dev_free(self.ctx.handle, self.ptr))      # a closed context (handle None) is accepted
             self.ptr = None
 
     def __del__(self):
@@ -96,13 +96,19 @@ class Context:
         return json.loads(buf.value.decode())
 
     def close(self):
-        """Destroys the context.  Every batch / tree / circuit / buffer created on it must have been freed before."""
+        """Drops this object's reference to the context (gl_ctx_destroy).  Batches / trees / circuits created on it hold
+        references of their own, so they stay valid and may be freed afterwards in any order; buffers from alloc() must be
+        freed before."""
         if self.handle:
             lib.gl_ctx_destroy(self.handle)
             self.handle = None
 
-    # no __del__: handles created on a context keep raw pointers into it and Python gives no destruction order (least of
-    # all at interpreter shutdown), so a context lives until close() or process exit
+    def __del__(self):
+        # safe in any finalisation order: the library tears the context down when its last handle is freed
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _default = None
@@ -112,9 +118,6 @@ def default_context():
     global _default
     if _default is None:
         _default = Context(0)
-        # handles created on the default context may be finalised in any order at interpreter exit:
-        # never tear the shared context down under them (the process is ending anyway)
-        _default.close = lambda: None
     return _default
 
 
@@ -623,6 +626,18 @@ class ProverPool:
         check(lib.gl_prover_pool_create(device, host.handle, lanes, ctypes.byref(h)))
         self.handle = h.value
 
+    @property
+    def circuit_digest(self):
+        out = np.empty(4, dtype=np.uint64)
+        check(lib.gl_circuit_digest(lib.gl_prover_pool_circuit(self.handle), _p(out)))
+        return out
+
+    @property
+    def constants_sigmas_cap(self):
+        out = np.empty((1 << self.host.desc.cap_height, 4), dtype=np.uint64)
+        check(lib.gl_circuit_constants_sigmas_cap(lib.gl_prover_pool_circuit(self.handle), _p(out)))
+        return out
+
     def prove_matmul(self, operands, filler_seeds=None):
         """operands: list of (a, b) m x m arrays; returns the list of Proof objects in the same order."""
         m2 = self.host.m ** 2
@@ -635,8 +650,10 @@ class ProverPool:
         pb = (ctypes.c_void_p * k)(*[x.ctypes.data for x in bb])
         seeds = None if filler_seeds is None else np.ascontiguousarray(np.asarray(filler_seeds, dtype=np.uint64))
         out = (ctypes.c_void_p * k)()
-        check(lib.gl_prover_pool_prove_matmul(self.handle, k, pa, pb, _p(seeds) if seeds is not None else None, out))
-        return [Proof(out[i], self.host.n) for i in range(k)]
+        st = lib.gl_prover_pool_prove_matmul(self.handle, k, pa, pb, _p(seeds) if seeds is not None else None, out)
+        proofs = [Proof(out[i], self.host.n) if out[i] else None for i in range(k)]      # owned from here on: freed even when a lane failed
+        check(st)
+        return proofs
 
     def close(self):
         if self.handle:

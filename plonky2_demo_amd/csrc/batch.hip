@@ -43,7 +43,7 @@ static int batch_alloc(gl_ctx* c, size_t ncols, size_t n, uint32_t rate_bits, ui
     GL_REQUIRE(cap_height <= lg + rate_bits, GL_ERR_ARG, "cap_height should be at most log2(leaves.len())");
     GL_TRY(c->activate());
     gl_batch* b = new gl_batch();
-    b->ctx = c; b->ncols = ncols; b->n = n; b->degree_log = lg; b->rate_bits = rate_bits; b->cap_height = cap_height;
+    b->ctx = c; c->retain(); b->ncols = ncols; b->n = n; b->degree_log = lg; b->rate_bits = rate_bits; b->cap_height = cap_height;
     int st = c->pool_alloc(ncols * n * sizeof(gl_t), (void**)&b->coeffs);
     if (st == GL_OK) st = c->pool_alloc(ncols * b->N() * sizeof(gl_t), (void**)&b->lde);
     if (st != GL_OK) { gl_batch_free(b); return st; }      // nothing leaks when the device is out of memory
@@ -147,5 +147,6 @@ extern "C" void gl_batch_free(gl_batch* b) {
     gl_merkle_release(b->ctx, &b->tree);
     if (b->coeffs) b->ctx->pool_release(b->coeffs);
     if (b->lde) b->ctx->pool_release(b->lde);
+    gl_ctx_release(b->ctx);
     delete b;
 }

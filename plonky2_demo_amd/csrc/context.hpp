@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <map>
 #include <tuple>
 #include <mutex>
@@ -13,6 +14,8 @@
 #include "gl64.cuh"
 #include "../../include/plonky2_mi355x.h"
 
+struct gl_ctx;
+void gl_ctx_release(gl_ctx* c);      // drops one reference (ntt.hip)
 extern thread_local std::string g_gl_last_error;
 int gl_fail(int code, const char* what, const char* file, int line);
 
@@ -48,6 +51,11 @@ struct GlPowTable {
 };
 
 struct gl_ctx {
+    // Lifetime: one reference for the creator (dropped by gl_ctx_destroy) plus one per live handle that points at this context
+    // (gl_batch, gl_merkle, gl_circuit, gl_fri, gl_matmul_witgen).  The context -- its stream, tables and allocator -- is torn
+    // down when the last reference goes, so handles may be freed after gl_ctx_destroy in any order.
+    std::atomic<int> refs{1};
+    void retain() { refs.fetch_add(1, std::memory_order_relaxed); }
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -93,6 +101,7 @@ struct gl_ctx {
     int ensure_pinned(size_t bytes);
     int ensure_dev_small(size_t bytes);
     int get_pow_table(gl_t base, gl_t scale, uint32_t hi_len, GlPowTable* out);
+    std::vector<gl_t*> retired_tables;      // superseded (shorter) power tables: possibly still in flight, freed with the context
     // small read-only index tables (Merkle leaf element offsets, ...) cached by content
     std::map<std::vector<uint64_t>, uint64_t*> offset_tables;
     int get_offsets_table(const uint64_t* host, size_t len, const uint64_t** d_out);

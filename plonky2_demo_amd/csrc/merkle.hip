@@ -9,6 +9,7 @@
 #include "context.hpp"
 #include "poseidon.cuh"
 #include <cstring>
+#include <memory>
 
 struct gl_merkle {
     gl_ctx* ctx = nullptr;
@@ -228,24 +229,20 @@ extern "C" int gl_merkle_new(gl_ctx* c, const uint64_t* h_leaves, size_t num_lea
     GL_REQUIRE((size_t(1) << lg) == num_leaves, GL_ERR_ARG, "number of leaves must be a power of two");
     GL_REQUIRE(cap_height <= lg, GL_ERR_ARG, "cap_height should be at most log2(leaves.len())");
     GL_TRY(c->activate());
-    gl_merkle* t = new gl_merkle();
-    t->ctx = c; t->num_leaves = num_leaves; t->leaf_len = leaf_len;
+    std::unique_ptr<gl_merkle, void (*)(gl_merkle*)> t(new gl_merkle(), gl_merkle_free);      // error paths free everything
+    t->ctx = c; c->retain(); t->num_leaves = num_leaves; t->leaf_len = leaf_len;
     const size_t bytes = num_leaves * leaf_len * sizeof(gl_t);
-    gl_t* cols = nullptr;
+    struct Scratch { gl_ctx* c; gl_t* p = nullptr; ~Scratch() { if (p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); } } } cols{c};
     GL_CHECK_HIP(hipMalloc((void**)&t->leaves, bytes));
-    GL_CHECK_HIP(hipMalloc((void**)&cols, bytes));
-    int st = gl_copy_h2d(c, t->leaves, h_leaves, bytes);
-    if (st != GL_OK) return st;
+    GL_CHECK_HIP(hipMalloc((void**)&cols.p, bytes));
+    GL_TRY(gl_copy_h2d(c, t->leaves, h_leaves, bytes));
     const uint64_t total = (uint64_t)num_leaves * leaf_len;
-    hipLaunchKernelGGL(k_rows_to_natural_cols, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, t->leaves, lg, (uint32_t)leaf_len, cols);
+    hipLaunchKernelGGL(k_rows_to_natural_cols, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, t->leaves, lg, (uint32_t)leaf_len, cols.p);
     GL_CHECK_HIP(hipGetLastError());
     std::vector<uint64_t> offs(leaf_len);
     for (size_t e = 0; e < leaf_len; e++) offs[e] = e * num_leaves;
-    st = gl_merkle_build(c, cols, offs.data(), (uint32_t)leaf_len, lg, cap_height, &t->tree);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(cols);
-    if (st != GL_OK) return st;
-    *out = t;
+    GL_TRY(gl_merkle_build(c, cols.p, offs.data(), (uint32_t)leaf_len, lg, cap_height, &t->tree));
+    *out = t.release();
     return GL_OK;
 }
 extern "C" int gl_merkle_cap(const gl_merkle* t, uint64_t* h_out) {
@@ -284,5 +281,6 @@ extern "C" void gl_merkle_free(gl_merkle* t) {
     (void)hipStreamSynchronize(t->ctx->stream);
     gl_merkle_release(t->ctx, &t->tree);
     if (t->leaves) (void)hipFree(t->leaves);
+    gl_ctx_release(t->ctx);
     delete t;
 }

@@ -1,6 +1,7 @@
 // NTT launchers, context management and the NTT / field entry points of the C ABI.
 #include "context.hpp"
 #include <atomic>
+#include <memory>
 #include "ntt.cuh"
 #include <cstdio>
 #include <cstring>
@@ -58,7 +59,8 @@ int gl_ctx::get_pow_table(gl_t base, gl_t scale, uint32_t hi_len, GlPowTable* ou
     uint32_t m = lo_len > hi_len ? lo_len : hi_len;
     hipLaunchKernelGGL(ntt_power_table, dim3((m + 255) / 256), dim3(256), 0, stream, base, scale, t.lo, t.hi, hi_len);
     GL_CHECK_HIP(hipGetLastError());
-    // an older, shorter table for the same key stays allocated until the context dies (it may be in flight)
+    // an older, shorter table for the same key may still be in flight: it is parked until the context dies
+    if (it != pow_tables.end()) retired_tables.push_back(it->second.lo);
     pow_tables[key] = t;
     *out = t;
     return GL_OK;
@@ -197,7 +199,8 @@ extern "C" int gl_ctx_create(int device, void* stream, gl_ctx** out) {
     if (e != hipSuccess || count == 0) return gl_fail(GL_ERR_HIP, "no HIP device available (this library has no CPU fallback)", __FILE__, __LINE__);
     GL_REQUIRE(device >= 0 && device < count, GL_ERR_ARG, "gl_ctx_create: bad device index");
     GL_CHECK_HIP(hipSetDevice(device));
-    gl_ctx* c = new gl_ctx();
+    std::unique_ptr<gl_ctx, void (*)(gl_ctx*)> holder(new gl_ctx(), gl_ctx_release);      // nothing leaks on an error path
+    gl_ctx* c = holder.get();
     c->device = device;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { GL_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -209,17 +212,19 @@ extern "C" int gl_ctx_create(int device, void* stream, gl_ctx** out) {
         hipLaunchKernelGGL(ntt_root_table, dim3(len / 256), dim3(256), 0, c->stream, w, c->tw_local[dir], len);
     }
     GL_CHECK_HIP(hipGetLastError());
-    *out = c;
+    *out = holder.release();
     return GL_OK;
 }
-extern "C" void gl_ctx_destroy(gl_ctx* c) {
-    if (!c) return;
+// the last reference is gone: nothing points at the context any more
+static void gl_ctx_teardown(gl_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (auto& r : c->timing_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (int d = 0; d < 2; d++) if (c->tw_local[d]) (void)hipFree(c->tw_local[d]);
     c->pool_trim();
-    for (auto& kv : c->pool_block_size) (void)hipFree(kv.first);      // blocks still held by live handles
+    for (auto& kv : c->pool_block_size) (void)hipFree(kv.first);      // only blocks leaked by a caller that dropped a handle without freeing it
     for (auto& kv : c->pow_tables) (void)hipFree(kv.second.lo);
+    for (gl_t* t : c->retired_tables) (void)hipFree(t);
     for (auto& kv : c->pass_tables) (void)hipFree(kv.second);
     for (auto& kv : c->offset_tables) (void)hipFree(kv.second);
     if (c->scratch) (void)hipFree(c->scratch);
@@ -227,6 +232,17 @@ extern "C" void gl_ctx_destroy(gl_ctx* c) {
     if (c->dev_small) (void)hipFree(c->dev_small);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+void gl_ctx_release(gl_ctx* c) {
+    if (c && c->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) gl_ctx_teardown(c);
+}
+// Drops the creator's reference.  Handles created on the context keep it alive (and usable through them) until the last of
+// them is freed; the caller must not pass `c` to any entry point after this call.
+extern "C" void gl_ctx_destroy(gl_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    gl_ctx_release(c);
 }
 extern "C" int gl_ctx_synchronize(gl_ctx* c) {
     GL_REQUIRE(c, GL_ERR_ARG, "null ctx");
@@ -247,9 +263,9 @@ extern "C" int gl_dev_alloc(gl_ctx* c, size_t bytes, void** d_out) {
     return GL_OK;
 }
 extern "C" int gl_dev_free(gl_ctx* c, void* d_ptr) {
-    GL_REQUIRE(c, GL_ERR_ARG, "null ctx");
-    GL_TRY(c->activate());
-    GL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    // plain device memory: a null context (already destroyed by the caller) is accepted, the whole device is drained instead
+    if (c) { GL_TRY(c->activate()); GL_CHECK_HIP(hipStreamSynchronize(c->stream)); }
+    else GL_CHECK_HIP(hipDeviceSynchronize());
     GL_CHECK_HIP(hipFree(d_ptr));
     return GL_OK;
 }

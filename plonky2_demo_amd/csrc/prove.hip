@@ -121,6 +121,7 @@ extern "C" void gl_circuit_free(gl_circuit* c) {
     if (c->cs_batch) gl_batch_free(c->cs_batch);
     if (c->d_sigmas) c->ctx->pool_release(c->d_sigmas);
     if (c->d_l0_coset) c->ctx->pool_release(c->d_l0_coset);
+    gl_ctx_release(c->ctx);
     delete c;
 }
 
@@ -129,7 +130,7 @@ extern "C" int gl_circuit_create(gl_ctx* ctx, const gl_circuit_desc* desc, const
     GL_TRY(validate_desc(*desc));
     GL_TRY(ctx->activate());
     std::unique_ptr<gl_circuit, void (*)(gl_circuit*)> c(new gl_circuit(), gl_circuit_free);
-    c->ctx = ctx; c->desc = *desc; c->n = size_t(1) << desc->degree_bits;
+    c->ctx = ctx; ctx->retain(); c->desc = *desc; c->n = size_t(1) << desc->degree_bits;
     const size_t n = c->n, ncs = desc->num_constants + 80;
     std::vector<const uint64_t*> cols(ncs);
     for (size_t k = 0; k < ncs; k++) cols[k] = h_cs + k * n;
@@ -357,8 +358,10 @@ struct gl_fri {
 };
 extern "C" void gl_fri_free(gl_fri* f) {
     if (!f) return;
-    if (f->ctx) (void)hipStreamSynchronize(f->ctx->stream);
-    delete f;
+    gl_ctx* ctx = f->ctx;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    delete f;                                  // its trees and buffers go back to the context's pool first
+    gl_ctx_release(ctx);
 }
 extern "C" int gl_fri_combine(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* const batches[4], const uint64_t zeta_in[2], const uint64_t alpha_in[2], gl_fri** out) {
     GL_TRY(check_phase_args(ctx, cir));
@@ -370,7 +373,7 @@ extern "C" int gl_fri_combine(gl_ctx* ctx, const gl_circuit* cir, const gl_batch
     for (int o = 0; o < 4; o++) GL_TRY(check_batch(cir, batches[o], want[o], "gl_fri_combine: oracle order is constants||sigmas, wires, Z||partial products, quotient"));
     hipStream_t st = ctx->stream;
     std::unique_ptr<gl_fri, void (*)(gl_fri*)> f(new gl_fri(), gl_fri_free);
-    f->ctx = ctx; f->desc = d; f->n = n; f->lgN = d.degree_bits + d.rate_bits;
+    f->ctx = ctx; ctx->retain(); f->desc = d; f->n = n; f->lgN = d.degree_bits + d.rate_bits;
     for (int o = 0; o < 4; o++) f->oracles[o] = batches[o];
     const gl2_t zeta = gl2_make(gl_canon(zeta_in[0]), gl_canon(zeta_in[1])), fri_alpha = gl2_make(gl_canon(alpha_in[0]), gl_canon(alpha_in[1]));
     const gl2_t gzeta = gl2_canon(gl2_scalar(zeta, gl_host_root_of_unity(d.degree_bits)));
@@ -492,7 +495,8 @@ extern "C" int gl_pow_grind(gl_ctx* ctx, const uint64_t sponge_state[12], const 
     pw.pos = input_len; pw.min_leading_zeros = min_leading_zeros; pw.result = d_res;
     // expected 2^pow_bits candidates: scan ascending windows of 2 * 2^pow_bits (86 % hit rate each) so that little work
     // is wasted; the window's atomicMin keeps the result the global minimum
-    const uint64_t batch = uint64_t(2) << min_leading_zeros;
+    // (a window is at most 2^30 candidates: the grid dimension is 32 bits)
+    const uint64_t batch = min_leading_zeros >= 29 ? (uint64_t(1) << 30) : (uint64_t(2) << min_leading_zeros);
     unsigned long long res = ~0ull;
     ctx->timing_begin("find proof-of-work witness");
     for (uint64_t base = 0; base < GL_P; base += batch) {

@@ -67,6 +67,7 @@ extern "C" void gl_matmul_witgen_free(gl_matmul_witgen* g) {
     }
     if (g->h_special) (void)hipHostFree(g->h_special);
     if (g->h_ab) (void)hipHostFree(g->h_ab);
+    gl_ctx_release(g->ctx);
     delete g;
 }
 
@@ -77,7 +78,7 @@ extern "C" int gl_matmul_witgen_create(gl_ctx* ctx, const gl_host_circuit* hc, g
     GL_REQUIRE(h.constant_row == h.first_poseidon_row + h.num_poseidon_rows + 1 && h.pi_row + 1 == h.constant_row, GL_ERR_INTERNAL,
                "matmul trace layout: PoseidonGate rows, PublicInputGate row and ConstantGate row must be consecutive");
     std::unique_ptr<gl_matmul_witgen, void (*)(gl_matmul_witgen*)> g(new gl_matmul_witgen(), gl_matmul_witgen_free);
-    g->ctx = ctx; g->hc = hc; g->R = h.num_poseidon_rows + 2;
+    g->ctx = ctx; ctx->retain(); g->hc = hc; g->R = h.num_poseidon_rows + 2;
     const size_t mm = h.m * h.m;
     GL_TRY(ctx->pool_alloc((h.mul_row.size() + 1) * sizeof(uint32_t), (void**)&g->d_mul_row));
     GL_TRY(ctx->pool_alloc((h.add_row.size() + 1) * sizeof(uint32_t), (void**)&g->d_add_row));

@@ -35,6 +35,15 @@ def test_product_never_touches_the_oracle():
                 assert not bad.search(src), "%s references the oracle" % f
 
 
+def test_oracle_never_touches_the_product():
+    """... and the checker shares no source with what it checks (its Poseidon tables are its own transcription of the
+    reference's, oracle/make_tables.py): a bug in a product header cannot be common-mode."""
+    orc_dir = os.path.join(ROOT, "oracle")
+    for f in os.listdir(orc_dir):
+        if f.endswith((".hpp", ".cpp", ".h")) or f == "Makefile":
+            assert "plonky2_demo_amd" not in open(os.path.join(orc_dir, f)).read(), "%s reaches into the product" % f
+
+
 def test_no_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():

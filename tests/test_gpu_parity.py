@@ -688,3 +688,90 @@ def test_prover_pool_matches_individual_proofs(gpu):
             pool.prove_matmul([(ops[0][0][:5], ops[0][1])])
     finally:
         pool.close()
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 4
+def test_config4_batch_of_512_proofs_m64(gpu):
+    # BASELINE.json configs[3] on one GPU: 512 independent random-witness proofs of the m = 64 circuit (operand seeds 0..511)
+    # through gl_prover_pool_prove_matmul (witness generation in HBM + prove per lane); every proof accepted by gl_verify, a
+    # sample of 16 byte-identical to the single-stream gl_prove of the same witness, and the Merkle caps pushed through the
+    # collective the multi-GPU run uses (sharding.gather_caps; a one-rank group here, world-size 2 in tests/test_sharding.py)
+    import torch.distributed as dist
+    from plonky2_demo_amd import sharding
+    p, ctx = gpu
+    m, count = 64, 512
+    hc = p.MatmulCircuit(m)
+
+    def operands(i):
+        rng = np.random.default_rng(i)
+        return rng.integers(0, 2**32 - 1, m * m, dtype=np.uint64), rng.integers(0, 2**32 - 1, m * m, dtype=np.uint64)
+
+    ops = [operands(i) for i in range(count)]
+    pool = p.ProverPool(hc, lanes=8)
+    try:
+        proofs = pool.prove_matmul(ops, list(range(count)))
+        cap, digest = pool.constants_sigmas_cap, pool.circuit_digest
+    finally:
+        pool.close()
+    assert len(proofs) == count and all(pr is not None for pr in proofs)
+    by = [pr.to_bytes() for pr in proofs]
+    assert len(set(by)) == count                                        # 512 different witnesses, 512 different proofs
+    for i in range(count):
+        assert hc.verify(by[i], cap, digest) == (True, ""), i
+    cd = hc.build(ctx)
+    assert (cd.circuit_digest == digest).all() and (cd.constants_sigmas_cap == cap).all()
+    for i in range(0, count, 32):                                       # 16 of them against the single-stream prover
+        a, b = ops[i]
+        wires, pis = hc.witness(a, b, filler_seed=i)
+        assert cd.prove(wires, pis).to_bytes() == by[i], i
+    caps = np.stack([pr.caps() for pr in proofs])
+    assert (caps.reshape(count, -1).view(np.uint8) == np.stack([np.frombuffer(x[:1536], dtype=np.uint8) for x in by])).all()   # the proof starts with its three caps
+    own_group = not dist.is_initialized()
+    if own_group:
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        gathered = sharding.gather_caps(caps, count)
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    assert gathered.shape == (count, 3, 16, 4) and (gathered == caps).all()
+
+
+# ------------------------------------------------------------------------------------------ handle / context lifetime
+_LIFETIME_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import plonky2_demo_amd as p
+from plonky2_demo_amd._lib import lib
+ctx = p.Context(0)
+rng = np.random.default_rng(1)
+vals = rng.integers(0, 2**63, (5, 256), dtype=np.uint64)
+batch = p.PolynomialBatch.from_values(vals, 3, False, 4, ctx=ctx)
+tree = p.MerkleTree(rng.integers(0, 2**63, (64, 7), dtype=np.uint64), 2, ctx=ctx)
+hc = p.MatmulCircuit(3)
+cd = hc.build(ctx)
+gen = hc.witness_generator(ctx)
+cap_before, dig_before, cs_before = batch.cap.copy(), cd.circuit_digest.copy(), cd.constants_sigmas_cap.copy()
+ctx.close()                      # the "wrong" order: the context goes first
+assert (batch.cap == cap_before).all()          # handles stay usable: they keep the context alive
+assert len(tree.prove(5)) == 4
+assert (cd.circuit_digest == dig_before).all() and (cd.constants_sigmas_cap == cs_before).all()
+del gen, cd
+batch.free()
+del tree                         # the last handle tears the context down
+ctx2 = p.Context(0); b2 = p.PolynomialBatch.from_values(vals, 3, False, 4, ctx=ctx2)
+assert (b2.cap == cap_before).all()
+print("lifetime ok")             # ctx2 / b2 are finalised by the interpreter in whatever order it likes
+"""
+
+
+def test_handles_may_outlive_and_be_freed_after_their_context(gpu):
+    # gl_ctx_destroy before gl_batch_free / gl_circuit_free / gl_merkle_free / gl_matmul_witgen_free used to be a
+    # use-after-free (abort at interpreter exit); handles now hold a reference.  Run in a child so that the exit code is seen.
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _LIFETIME_SCRIPT % root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "lifetime ok" in r.stdout

@@ -251,3 +251,47 @@ def test_partial_products_reference_vector(orc):
         lib.orc_check_partial_products(vp(v), vp(ones), ctypes.c_size_t(6), vp(pps), ctypes.c_size_t(len(pps)), ctypes.c_uint64(1),
                                        ctypes.c_uint64(721), ctypes.c_size_t(max_degree), vp(chk))
         assert any(int(x) for x in chk[:c])
+
+
+# ---------------------------------------------------------------------- Poseidon tables pinned to reference-held data
+def _parse_tables(path):
+    import re
+    text = open(path).read()
+    out = {}
+    for m in re.finditer(r"(?:POSEIDON_TABLE(?:32)?\((\w+), \d+\)|static const uint64_t (\w+)\[\d+\]) = \{(.*?)\};", text, re.S):
+        out[m.group(1) or m.group(2)] = [int(x.rstrip("uUL"), 0) for x in re.findall(r"0x[0-9a-fA-F]+|\b\d+u?\b", m.group(3))]
+    return out
+
+
+def test_poseidon_tables_equal_the_reference_tables():
+    """The five FAST_PARTIAL_* tables the reference holds (plonky2/src/hash/poseidon_goldilocks.rs:27-215, committed as data in
+    tests/golden/poseidon_fast_tables.json) pin (a) what tools/gen_poseidon_constants.py derives from first principles,
+    (b) the product's generated csrc/poseidon_constants.inc and (c) the oracle's own transcribed copy -- the KATs pin only
+    the permutation, these tables are what the PoseidonGate constraint code (gates/poseidon.rs:193-272) is written against."""
+    import json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = json.load(open(os.path.join(root, "tests", "golden", "poseidon_fast_tables.json")))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_poseidon_constants as g
+    rc = g.load_round_constants()
+    T = g.derive(rc)
+    flat = lambda rows: [x for r in rows for x in r]
+    assert T["first"] == ref["FAST_PARTIAL_FIRST_ROUND_CONSTANT"]
+    assert T["ks"] == ref["FAST_PARTIAL_ROUND_CONSTANTS"]
+    assert flat(T["cols_w"]) == ref["FAST_PARTIAL_ROUND_VS"]
+    assert flat(T["rows_v"]) == ref["FAST_PARTIAL_ROUND_W_HATS"]
+    assert flat([[T["init"][c][r] for c in range(11)] for r in range(11)]) == ref["FAST_PARTIAL_ROUND_INITIAL_MATRIX"]
+    assert g.MDS_CIRC == ref["MDS_MATRIX_CIRC"] and g.MDS_DIAG == ref["MDS_MATRIX_DIAG"]
+    want = {"POSEIDON_RC": flat(rc), "POSEIDON_MDS_CIRC": ref["MDS_MATRIX_CIRC"], "POSEIDON_MDS_DIAG": ref["MDS_MATRIX_DIAG"],
+            "POSEIDON_PARTIAL_FIRST_RC": ref["FAST_PARTIAL_FIRST_ROUND_CONSTANT"], "POSEIDON_PARTIAL_RC": ref["FAST_PARTIAL_ROUND_CONSTANTS"],
+            "POSEIDON_PARTIAL_INIT": ref["FAST_PARTIAL_ROUND_INITIAL_MATRIX"], "POSEIDON_PARTIAL_ROW": ref["FAST_PARTIAL_ROUND_W_HATS"],
+            "POSEIDON_PARTIAL_COL": ref["FAST_PARTIAL_ROUND_VS"]}
+    product = _parse_tables(os.path.join(root, "plonky2_demo_amd", "csrc", "poseidon_constants.inc"))
+    oracle = _parse_tables(os.path.join(root, "oracle", "gl_poseidon_tables.hpp"))
+    for name, vals in want.items():
+        assert product[name] == vals, "product table %s differs from the reference's" % name
+        assert oracle[name] == vals, "oracle table %s differs from the reference's" % name
+    # the GPU-only grouped form (three partial rounds at a time) has no reference counterpart: it is validated against the
+    # textbook permutation by the generator itself and by the KATs on the device
+    G = g.derive_groups(rc, T["M"])
+    assert product["POSEIDON_G3_M3"] == flat(G["M3"]) and product["POSEIDON_G3_K"] == flat(G["K"])
