@@ -1,0 +1,267 @@
+// Goldilocks products for gfx950, three at a time (device only).
+//
+// What the instruction stream costs on this chip (tools/ubench/valu_class.hip, valu_mix.hip, gl_prims.hip; profiles/README.md):
+// the 64-bit / multiply / compare instructions (v_mad_u64_u32, v_lshl_add_u64, v_cmp_*, v_lshlrev_b32 ...) take ~4.2 cycles of the
+// SIMD each; the 32-bit add / sub / carry / select / logic instructions take ~2.4 -- but only in runs of their own kind -- and
+// a VALU instruction that reads a carry or mask another VALU instruction wrote needs two instructions in between (else s_nop).
+// One product is 4 multiply-adds for the 128-bit result, 3 carry adds, 1 multiply-add for lo + hl * EPS (the multiply by
+// EPS = 2^32 - 1, the 64-bit add and its carry in one instruction), 2 borrow subtractions for - hh and one two-sided fix-up
+// built from the two carry masks on the scalar unit: 15 instructions instead of the compiler's 24 -- and with THREE
+// independent products interleaved the carry chains need no wait states and the cheap instructions form runs.
+//
+// Same function as gl_mul (field/src/goldilocks_field.rs:355-369 reduce128): any u64 representatives in, a u64
+// representative out (CANON: the canonical one).
+#pragma once
+#include "gl64.cuh"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ gl_t glx_mk64(uint32_t lo, uint32_t hi) { return ((gl_t)hi << 32) | lo; }
+
+template <bool CANON>
+__device__ __forceinline__ void glx_mul3(gl_t aA, gl_t bA, gl_t aB, gl_t bB, gl_t aC, gl_t bC, gl_t& rA, gl_t& rB, gl_t& rC) {
+    typedef uint32_t u32;
+    gl_t p00A, midA, p11A, p00B, midB, p11B, p00C, midC, p11C;
+    uint64_t cmA, cmB, cmC;              // carries of the cross-term sums, worth 2^96 = -1 each
+    asm("v_mad_u64_u32 %[p00A], vcc, %[a0A], %[b0A], 0\n\t"
+        "v_mad_u64_u32 %[p00B], vcc, %[a0B], %[b0B], 0\n\t"
+        "v_mad_u64_u32 %[p00C], vcc, %[a0C], %[b0C], 0\n\t"
+        "v_mad_u64_u32 %[midA], vcc, %[a0A], %[b1A], 0\n\t"
+        "v_mad_u64_u32 %[midB], vcc, %[a0B], %[b1B], 0\n\t"
+        "v_mad_u64_u32 %[midC], vcc, %[a0C], %[b1C], 0\n\t"
+        "v_mad_u64_u32 %[p11A], vcc, %[a1A], %[b1A], 0\n\t"
+        "v_mad_u64_u32 %[p11B], vcc, %[a1B], %[b1B], 0\n\t"
+        "v_mad_u64_u32 %[p11C], vcc, %[a1C], %[b1C], 0\n\t"
+        "v_mad_u64_u32 %[midA], %[cmA], %[a1A], %[b0A], %[midA]\n\t"
+        "v_mad_u64_u32 %[midB], %[cmB], %[a1B], %[b0B], %[midB]\n\t"
+        "v_mad_u64_u32 %[midC], %[cmC], %[a1C], %[b0C], %[midC]"
+        : [p00A] "=&v"(p00A), [midA] "=&v"(midA), [p11A] "=&v"(p11A), [cmA] "=&s"(cmA),
+          [p00B] "=&v"(p00B), [midB] "=&v"(midB), [p11B] "=&v"(p11B), [cmB] "=&s"(cmB),
+          [p00C] "=&v"(p00C), [midC] "=&v"(midC), [p11C] "=&v"(p11C), [cmC] "=&s"(cmC)
+        : [a0A] "v"((u32)aA), [a1A] "v"((u32)(aA >> 32)), [b0A] "v"((u32)bA), [b1A] "v"((u32)(bA >> 32)),
+          [a0B] "v"((u32)aB), [a1B] "v"((u32)(aB >> 32)), [b0B] "v"((u32)bB), [b1B] "v"((u32)(bB >> 32)),
+          [a0C] "v"((u32)aC), [a1C] "v"((u32)(aC >> 32)), [b0C] "v"((u32)bC), [b1C] "v"((u32)(bC >> 32))
+        : "vcc");
+    // product words: w0 = p00.lo, w1 = p00.hi + mid.lo, w2 = p11.lo + mid.hi + carry, w3 = p11.hi + carry (+ cm, kept apart).
+    // Computed in place (tied operands): (w0, w1) stays the register pair of p00 and feeds the next multiply-add without a move.
+    u32 w1A = (u32)(p00A >> 32), w2A = (u32)p11A, w3A = (u32)(p11A >> 32);
+    u32 w1B = (u32)(p00B >> 32), w2B = (u32)p11B, w3B = (u32)(p11B >> 32);
+    u32 w1C = (u32)(p00C >> 32), w2C = (u32)p11C, w3C = (u32)(p11C >> 32);
+    uint64_t sB, sC;
+    asm("v_add_co_u32 %[w1A], vcc, %[w1A], %[m0A]\n\t"
+        "v_add_co_u32_e64 %[w1B], %[sB], %[w1B], %[m0B]\n\t"
+        "v_add_co_u32_e64 %[w1C], %[sC], %[w1C], %[m0C]\n\t"
+        "v_addc_co_u32 %[w2A], vcc, %[w2A], %[m1A], vcc\n\t"
+        "v_addc_co_u32_e64 %[w2B], %[sB], %[w2B], %[m1B], %[sB]\n\t"
+        "v_addc_co_u32_e64 %[w2C], %[sC], %[w2C], %[m1C], %[sC]\n\t"
+        "v_addc_co_u32 %[w3A], vcc, 0, %[w3A], vcc\n\t"                 // no carry out: a product is < 2^128
+        "v_addc_co_u32_e64 %[w3B], %[sB], 0, %[w3B], %[sB]\n\t"
+        "v_addc_co_u32_e64 %[w3C], %[sC], 0, %[w3C], %[sC]"
+        : [w1A] "+v"(w1A), [w2A] "+v"(w2A), [w3A] "+v"(w3A), [w1B] "+v"(w1B), [w2B] "+v"(w2B), [w3B] "+v"(w3B),
+          [w1C] "+v"(w1C), [w2C] "+v"(w2C), [w3C] "+v"(w3C), [sB] "=&s"(sB), [sC] "=&s"(sC)
+        : [m0A] "v"((u32)midA), [m1A] "v"((u32)(midA >> 32)), [m0B] "v"((u32)midB), [m1B] "v"((u32)(midB >> 32)),
+          [m0C] "v"((u32)midC), [m1C] "v"((u32)(midC >> 32))
+        : "vcc");
+    // z = lo + hl * EPS (mod 2^64), carry c
+    const gl_t loA = glx_mk64((u32)p00A, w1A), loB = glx_mk64((u32)p00B, w1B), loC = glx_mk64((u32)p00C, w1C);
+    gl_t zA, zB, zC;
+    uint64_t cA, cB, cC;
+    asm("v_mad_u64_u32 %[zA], %[cA], %[w2A], -1, %[loA]\n\t"
+        "v_mad_u64_u32 %[zB], %[cB], %[w2B], -1, %[loB]\n\t"
+        "v_mad_u64_u32 %[zC], %[cC], %[w2C], -1, %[loC]"
+        : [zA] "=&v"(zA), [cA] "=&s"(cA), [zB] "=&v"(zB), [cB] "=&s"(cB), [zC] "=&v"(zC), [cC] "=&s"(cC)
+        : [w2A] "v"(w2A), [loA] "v"(loA), [w2B] "v"(w2B), [loB] "v"(loB), [w2C] "v"(w2C), [loC] "v"(loC));
+    // y = z - hh (hh = w3 + cm) mod 2^64, borrow b.  The true value is y + (c - b) 2^64: c > b -> add EPS, b > c -> subtract EPS
+    // (neither overflows: goldilocks_field.rs:355-369); both results are < p, with c = b the value y may still be >= p.
+    u32 y0A = (u32)zA, y1A = (u32)(zA >> 32), y0B = (u32)zB, y1B = (u32)(zB >> 32), y0C = (u32)zC, y1C = (u32)(zC >> 32);
+    uint64_t bwA, bwB, bwC;
+    asm("v_subb_co_u32_e64 %[y0A], vcc, %[y0A], %[w3A], %[cmA]\n\t"
+        "v_subb_co_u32_e64 %[y0B], %[bwB], %[y0B], %[w3B], %[cmB]\n\t"
+        "v_subb_co_u32_e64 %[y0C], %[bwC], %[y0C], %[w3C], %[cmC]\n\t"
+        "v_subbrev_co_u32_e64 %[y1A], %[bwA], 0, %[y1A], vcc\n\t"
+        "v_subbrev_co_u32_e64 %[y1B], %[bwB], 0, %[y1B], %[bwB]\n\t"
+        "v_subbrev_co_u32_e64 %[y1C], %[bwC], 0, %[y1C], %[bwC]"
+        : [y0A] "+v"(y0A), [y1A] "+v"(y1A), [y0B] "+v"(y0B), [y1B] "+v"(y1B), [y0C] "+v"(y0C), [y1C] "+v"(y1C),
+          [bwA] "=&s"(bwA), [bwB] "=&s"(bwB), [bwC] "=&s"(bwC)
+        : [w3A] "v"(w3A), [cmA] "s"(cmA), [w3B] "v"(w3B), [cmB] "s"(cmB), [w3C] "v"(w3C), [cmC] "s"(cmC)
+        : "vcc");
+    u32 f0A, f1A, f0B, f1B, f0C, f1C;
+    uint64_t tA, tB, tC;
+    // N = b & ~c: subtract EPS.  P = c & ~b: add EPS.  CANON: y >= p and nothing subtracted: add EPS as well (= y - p mod 2^64).
+    // (f1:f0) = +EPS, -EPS (mod 2^64) or 0; the scalar unit combines the masks while the vector unit is busy elsewhere
+#define GLX_MUL3_TAIL                                                     \
+        "v_cndmask_b32_e64 %[f1A], 0, -1, %[tA]\n\t"                      \
+        "v_cndmask_b32_e64 %[f1B], 0, -1, %[tB]\n\t"                      \
+        "v_cndmask_b32_e64 %[f1C], 0, -1, %[tC]\n\t"                      \
+        "v_cndmask_b32_e64 %[f0A], 0, -1, %[bwA]\n\t"                     \
+        "v_cndmask_b32_e64 %[f0B], 0, -1, %[bwB]\n\t"                     \
+        "v_cndmask_b32_e64 %[f0C], 0, -1, %[bwC]\n\t"                     \
+        "v_sub_u32 %[f0A], %[f0A], %[f1A]\n\t"                            \
+        "v_sub_u32 %[f0B], %[f0B], %[f1B]\n\t"                            \
+        "v_sub_u32 %[f0C], %[f0C], %[f1C]\n\t"                            \
+        "v_add_co_u32 %[y0A], vcc, %[y0A], %[f0A]\n\t"                    \
+        "v_add_co_u32_e64 %[y0B], %[tB], %[y0B], %[f0B]\n\t"              \
+        "v_add_co_u32_e64 %[y0C], %[tC], %[y0C], %[f0C]\n\t"              \
+        "v_addc_co_u32 %[y1A], vcc, %[y1A], %[f1A], vcc\n\t"              \
+        "v_addc_co_u32_e64 %[y1B], %[tB], %[y1B], %[f1B], %[tB]\n\t"      \
+        "v_addc_co_u32_e64 %[y1C], %[tC], %[y1C], %[f1C], %[tC]"
+    if constexpr (CANON) {
+        const gl_t yA = glx_mk64(y0A, y1A), yB = glx_mk64(y0B, y1B), yC = glx_mk64(y0C, y1C);
+        uint64_t gA, gB, gC;
+        asm("v_cmp_gt_u64_e64 %[gA], %[yA], %[pm1]\n\t"
+            "v_cmp_gt_u64_e64 %[gB], %[yB], %[pm1]\n\t"
+            "v_cmp_gt_u64_e64 %[gC], %[yC], %[pm1]"
+            : [gA] "=&s"(gA), [gB] "=&s"(gB), [gC] "=&s"(gC)
+            : [yA] "v"(yA), [yB] "v"(yB), [yC] "v"(yC), [pm1] "s"(GL_P - 1));
+        asm("s_andn2_b64 %[tA], %[bwA], %[cA]\n\t"
+            "s_andn2_b64 %[tB], %[bwB], %[cB]\n\t"
+            "s_andn2_b64 %[tC], %[bwC], %[cC]\n\t"
+            "s_andn2_b64 %[bwA], %[cA], %[bwA]\n\t"
+            "s_andn2_b64 %[bwB], %[cB], %[bwB]\n\t"
+            "s_andn2_b64 %[bwC], %[cC], %[bwC]\n\t"
+            "s_andn2_b64 %[gA], %[gA], %[tA]\n\t"
+            "s_andn2_b64 %[gB], %[gB], %[tB]\n\t"
+            "s_andn2_b64 %[gC], %[gC], %[tC]\n\t"
+            "s_or_b64 %[bwA], %[gA], %[bwA]\n\t"
+            "s_or_b64 %[bwB], %[gB], %[bwB]\n\t"
+            "s_or_b64 %[bwC], %[gC], %[bwC]\n\t"
+            GLX_MUL3_TAIL
+            : [f0A] "=&v"(f0A), [f1A] "=&v"(f1A), [f0B] "=&v"(f0B), [f1B] "=&v"(f1B), [f0C] "=&v"(f0C), [f1C] "=&v"(f1C),
+              [y0A] "+v"(y0A), [y1A] "+v"(y1A), [y0B] "+v"(y0B), [y1B] "+v"(y1B), [y0C] "+v"(y0C), [y1C] "+v"(y1C),
+              [tA] "=&s"(tA), [tB] "=&s"(tB), [tC] "=&s"(tC), [gA] "+s"(gA), [gB] "+s"(gB), [gC] "+s"(gC),
+              [bwA] "+s"(bwA), [bwB] "+s"(bwB), [bwC] "+s"(bwC)
+            : [cA] "s"(cA), [cB] "s"(cB), [cC] "s"(cC)
+            : "vcc", "scc");
+    } else {
+        asm("s_andn2_b64 %[tA], %[bwA], %[cA]\n\t"
+            "s_andn2_b64 %[tB], %[bwB], %[cB]\n\t"
+            "s_andn2_b64 %[tC], %[bwC], %[cC]\n\t"
+            "s_andn2_b64 %[bwA], %[cA], %[bwA]\n\t"
+            "s_andn2_b64 %[bwB], %[cB], %[bwB]\n\t"
+            "s_andn2_b64 %[bwC], %[cC], %[bwC]\n\t"
+            GLX_MUL3_TAIL
+            : [f0A] "=&v"(f0A), [f1A] "=&v"(f1A), [f0B] "=&v"(f0B), [f1B] "=&v"(f1B), [f0C] "=&v"(f0C), [f1C] "=&v"(f1C),
+              [y0A] "+v"(y0A), [y1A] "+v"(y1A), [y0B] "+v"(y0B), [y1B] "+v"(y1B), [y0C] "+v"(y0C), [y1C] "+v"(y1C),
+              [tA] "=&s"(tA), [tB] "=&s"(tB), [tC] "=&s"(tC), [bwA] "+s"(bwA), [bwB] "+s"(bwB), [bwC] "+s"(bwC)
+            : [cA] "s"(cA), [cB] "s"(cB), [cC] "s"(cC)
+            : "vcc", "scc");
+    }
+#undef GLX_MUL3_TAIL
+    rA = glx_mk64(y0A, y1A); rB = glx_mk64(y0B, y1B); rC = glx_mk64(y0C, y1C);
+}
+
+// One product (the same arithmetic, with the wait states the lone carry chains need): for counts that are not multiples of three
+template <bool CANON>
+__device__ __forceinline__ gl_t glx_mul(gl_t a, gl_t b) {
+    typedef uint32_t u32;
+    gl_t p00, mid, p11;
+    uint64_t cm;
+    asm("v_mad_u64_u32 %0, vcc, %4, %6, 0\n\t"
+        "v_mad_u64_u32 %1, vcc, %4, %7, 0\n\t"
+        "v_mad_u64_u32 %2, vcc, %5, %7, 0\n\t"
+        "v_mad_u64_u32 %1, %3, %5, %6, %1"
+        : "=&v"(p00), "=&v"(mid), "=&v"(p11), "=&s"(cm)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+        : "vcc");
+    u32 w1 = (u32)(p00 >> 32), w2 = (u32)p11, w3 = (u32)(p11 >> 32);
+    asm("v_add_co_u32 %[w1], vcc, %[w1], %[m0]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %[w2], vcc, %[w2], %[m1], vcc\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %[w3], vcc, 0, %[w3], vcc"
+        : [w1] "+v"(w1), [w2] "+v"(w2), [w3] "+v"(w3)
+        : [m0] "v"((u32)mid), [m1] "v"((u32)(mid >> 32))
+        : "vcc");
+    const gl_t lo = glx_mk64((u32)p00, w1);
+    gl_t z;
+    uint64_t c, bw, t, g;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"(w2), "v"(lo));
+    u32 y0 = (u32)z, y1 = (u32)(z >> 32), f0, f1;
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32_e64 %[y0], vcc, %[y0], %[w3], %[cm]\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32_e64 %[y1], %[bw], 0, %[y1], vcc"
+        : [y0] "+v"(y0), [y1] "+v"(y1), [bw] "=&s"(bw) : [w3] "v"(w3), [cm] "s"(cm) : "vcc");
+    if constexpr (CANON) {
+        const gl_t y = glx_mk64(y0, y1);
+        asm("v_cmp_gt_u64_e64 %0, %1, %2" : "=s"(g) : "v"(y), "s"(GL_P - 1));
+        asm("s_nop 0\n\t"
+            "s_andn2_b64 %[t], %[bw], %[c]\n\t"
+            "s_andn2_b64 %[bw], %[c], %[bw]\n\t"
+            "s_andn2_b64 %[g], %[g], %[t]\n\t"
+            "s_or_b64 %[bw], %[g], %[bw]"
+            : [t] "=&s"(t), [g] "+s"(g), [bw] "+s"(bw) : [c] "s"(c) : "scc");
+    } else {
+        asm("s_nop 0\n\t"
+            "s_andn2_b64 %[t], %[bw], %[c]\n\t"
+            "s_andn2_b64 %[bw], %[c], %[bw]"
+            : [t] "=&s"(t), [bw] "+s"(bw) : [c] "s"(c) : "scc");
+    }
+    asm("v_cndmask_b32_e64 %[f1], 0, -1, %[t]\n\t"
+        "v_cndmask_b32_e64 %[f0], 0, -1, %[bw]\n\t"
+        "v_sub_u32 %[f0], %[f0], %[f1]\n\t"
+        "v_add_co_u32 %[y0], vcc, %[y0], %[f0]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %[y1], vcc, %[y1], %[f1], vcc"
+        : [f0] "=&v"(f0), [f1] "=&v"(f1), [y0] "+v"(y0), [y1] "+v"(y1)
+        : [t] "s"(t), [bw] "s"(bw)
+        : "vcc");
+    return glx_mk64(y0, y1);
+}
+
+// lo + top * EPS (mod p) with one fix-up, valid while lo + top * EPS < 2^65 - 2^32 (goldilocks_field.rs:346-351 reduce96):
+// v_mad_u64_u32 does the multiply by EPS, the 64-bit add and the carry in one instruction
+__device__ __forceinline__ gl_t glx_reduce96(gl_t lo, uint32_t top) {
+    gl_t z; uint64_t c; uint32_t e;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"(top), "v"(lo));
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(e) : "s"(c));
+    return z + (gl_t)e;
+}
+// al + ah 2^32 (al, ah < 2^63) -> one word: the Poseidon MDS accumulators
+__device__ __forceinline__ gl_t glx_acc_reduce(gl_t al, gl_t ah) {
+    uint32_t w1 = (uint32_t)(al >> 32), top = (uint32_t)(ah >> 32);
+    asm("v_add_co_u32 %[w1], vcc, %[w1], %[ahl]\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %[top], vcc, 0, %[top], vcc"
+        : [w1] "+v"(w1), [top] "+v"(top)
+        : [ahl] "v"((uint32_t)ah)
+        : "vcc");
+    return glx_reduce96(glx_mk64((uint32_t)al, w1), top);
+}
+// three accumulator pairs at once (no wait states)
+__device__ __forceinline__ void glx_acc_reduce3(gl_t alA, gl_t ahA, gl_t alB, gl_t ahB, gl_t alC, gl_t ahC, gl_t& rA, gl_t& rB, gl_t& rC) {
+    typedef uint32_t u32;
+    u32 w1A = (u32)(alA >> 32), topA = (u32)(ahA >> 32), w1B = (u32)(alB >> 32), topB = (u32)(ahB >> 32), w1C = (u32)(alC >> 32), topC = (u32)(ahC >> 32);
+    uint64_t sB, sC;
+    asm("v_add_co_u32 %[w1A], vcc, %[w1A], %[lA]\n\t"
+        "v_add_co_u32_e64 %[w1B], %[sB], %[w1B], %[lB]\n\t"
+        "v_add_co_u32_e64 %[w1C], %[sC], %[w1C], %[lC]\n\t"
+        "v_addc_co_u32 %[tA], vcc, 0, %[tA], vcc\n\t"
+        "v_addc_co_u32_e64 %[tB], %[sB], 0, %[tB], %[sB]\n\t"
+        "v_addc_co_u32_e64 %[tC], %[sC], 0, %[tC], %[sC]"
+        : [w1A] "+v"(w1A), [tA] "+v"(topA), [w1B] "+v"(w1B), [tB] "+v"(topB), [w1C] "+v"(w1C), [tC] "+v"(topC), [sB] "=&s"(sB), [sC] "=&s"(sC)
+        : [lA] "v"((u32)ahA), [lB] "v"((u32)ahB), [lC] "v"((u32)ahC)
+        : "vcc");
+    const gl_t loA = glx_mk64((u32)alA, w1A), loB = glx_mk64((u32)alB, w1B), loC = glx_mk64((u32)alC, w1C);
+    gl_t zA, zB, zC;
+    uint64_t cA, cB, cC;
+    u32 eA, eB, eC;
+    asm("v_mad_u64_u32 %[zA], %[cA], %[tA], -1, %[loA]\n\t"
+        "v_mad_u64_u32 %[zB], %[cB], %[tB], -1, %[loB]\n\t"
+        "v_mad_u64_u32 %[zC], %[cC], %[tC], -1, %[loC]\n\t"
+        "v_cndmask_b32_e64 %[eA], 0, -1, %[cA]\n\t"
+        "v_cndmask_b32_e64 %[eB], 0, -1, %[cB]\n\t"
+        "v_cndmask_b32_e64 %[eC], 0, -1, %[cC]"
+        : [zA] "=&v"(zA), [cA] "=&s"(cA), [zB] "=&v"(zB), [cB] "=&s"(cB), [zC] "=&v"(zC), [cC] "=&s"(cC), [eA] "=&v"(eA), [eB] "=&v"(eB), [eC] "=&v"(eC)
+        : [tA] "v"(topA), [loA] "v"(loA), [tB] "v"(topB), [loB] "v"(loB), [tC] "v"(topC), [loC] "v"(loC));
+    rA = zA + (gl_t)eA; rB = zB + (gl_t)eB; rC = zC + (gl_t)eC;
+}
+#elif defined(__HIPCC__)
+// host pass of a .hip file: kernels that call these must still parse
+template <bool CANON>
+__device__ void glx_mul3(gl_t aA, gl_t bA, gl_t aB, gl_t bB, gl_t aC, gl_t bC, gl_t& rA, gl_t& rB, gl_t& rC);
+template <bool CANON>
+__device__ gl_t glx_mul(gl_t a, gl_t b);
+__device__ gl_t glx_reduce96(gl_t lo, uint32_t top);
+__device__ gl_t glx_acc_reduce(gl_t al, gl_t ah);
+__device__ void glx_acc_reduce3(gl_t alA, gl_t ahA, gl_t alB, gl_t ahB, gl_t alC, gl_t ahC, gl_t& rA, gl_t& rB, gl_t& rC);
+#endif

@@ -27,8 +27,9 @@ static uint32_t gl_coop_max_nodes() {
 
 __device__ __forceinline__ uint32_t d_bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
-// digest of natural row r -> digests[bitrev(r)]
-__global__ __launch_bounds__(256) void k_merkle_leaves(const gl_t* __restrict__ base, const uint64_t* __restrict__ offsets,
+// digest of natural row r -> digests[bitrev(r)].  WPE: waves per SIMD the register allocation must leave room for
+template <int WPE>
+__global__ __launch_bounds__(256, WPE) void k_merkle_leaves(const gl_t* __restrict__ base, const uint64_t* __restrict__ offsets,
                                                        uint32_t leaf_len, uint32_t lg_leaves, gl_t* __restrict__ digests) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= (1u << lg_leaves)) return;
@@ -167,7 +168,11 @@ int gl_merkle_build(gl_ctx* c, const gl_t* base, const uint64_t* host_offsets, u
     c->timing_begin("merkle_leaf_hash");
     // below gl_coop_max_nodes() one-lane-per-hash launches cannot fill the 1024 SIMDs: use 16 lanes per hash (latency / 3)
     if (n <= gl_coop_max_nodes()) hipLaunchKernelGGL(k_merkle_leaves_coop, dim3((n * 16 + 255) / 256), dim3(256), 0, c->stream, base, d_off, leaf_len, lg_leaves, out->level_ptr(0));
-    else hipLaunchKernelGGL(k_merkle_leaves, dim3((n + 255) / 256), dim3(256), 0, c->stream, base, d_off, leaf_len, lg_leaves, out->level_ptr(0));
+    else {
+        static const int wpe = [] { const char* e = getenv("GL_LEAF_WPE"); return e ? atoi(e) : 5; }();      // tuning knob
+        auto kern = wpe >= 8 ? k_merkle_leaves<8> : wpe == 7 ? k_merkle_leaves<7> : wpe == 6 ? k_merkle_leaves<6> : wpe == 4 ? k_merkle_leaves<4> : k_merkle_leaves<5>;
+        hipLaunchKernelGGL(kern, dim3((n + 255) / 256), dim3(256), 0, c->stream, base, d_off, leaf_len, lg_leaves, out->level_ptr(0));
+    }
     c->timing_end();
     GL_CHECK_HIP(hipGetLastError());
     c->timing_begin("merkle_levels");

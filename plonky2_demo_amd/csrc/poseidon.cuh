@@ -12,6 +12,7 @@
 #pragma once
 #include <stdlib.h>
 #include "gl64.cuh"
+#include "gl64_mul3.cuh"
 #include "poseidon_constants.h"
 
 #if defined(__HIPCC__)
@@ -30,8 +31,13 @@
 #endif
 
 GL_HD gl_t psd_sbox(gl_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const gl_t x2 = glx_mul<false>(x, x), x4 = glx_mul<false>(x2, x2), x3 = glx_mul<false>(x, x2);
+    return glx_mul<false>(x3, x4);
+#else
     gl_t x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x, x2);
     return gl_mul(x3, x4);
+#endif
 }
 
 // Host formulation (the Challenger, public_inputs_hash, the witness generator's sponge rows, the verifier): 64 x 64 -> 128
@@ -124,6 +130,18 @@ GL_HD void psd_partial_rounds(gl_t (&s)[12]) {
     }
 }
 
+// al + ah 2^32 (al, ah < 2^63) reduced to one word
+GL_HD gl_t psd_acc_reduce(gl_t al, gl_t ah) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return glx_acc_reduce(al, ah);      // carry add, carry add, multiply-add by EPS with carry, select, add: 5 instructions
+#else
+    const uint32_t al_hi = (uint32_t)(al >> 32), ah_lo = (uint32_t)ah;
+    const uint32_t mid = al_hi + ah_lo;
+    const uint32_t top = (uint32_t)(ah >> 32) + (mid < ah_lo ? 1u : 0u);
+    return gl_reduce96(((gl_t)mid << 32) | (uint32_t)al, top);
+#endif
+}
+
 // GPU formulation of the permutation: the TEXTBOOK round structure (poseidon.rs:573-596 `poseidon_naive`: every round is
 // constants, S-box, full MDS), not the factorised partial rounds.  On gfx950 a 64 x 64 modular multiply costs ~26 VALU
 // instructions while the MDS layer, whose entries are 6-bit constants, is 288 single-instruction multiply-adds plus 12
@@ -143,6 +161,26 @@ GL_HD void psd_mds_then_constants(gl_t (&s)[12], const gl_t* __restrict__ rc) {
     uint32_t lo[12], hi[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) { lo[i] = (uint32_t)s[i]; hi[i] = (uint32_t)(s[i] >> 32); }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // three output words at a time: their accumulators are reduced together (glx_acc_reduce3: no wait states)
+#pragma unroll
+    for (int r0 = 0; r0 < 12; r0 += 3) {
+        gl_t al[3], ah[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int r = r0 + k;
+            al[k] = 0; ah[k] = 0;          // each < (256 + 8 + 1) * 2^32 < 2^41
+            if (WITH_RC) { const gl_t c = rc[r]; al[k] = (uint32_t)c; ah[k] = c >> 32; }
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                al[k] += (gl_t)lo[(i + r) % 12] * circ[i];
+                ah[k] += (gl_t)hi[(i + r) % 12] * circ[i];
+            }
+            if (r == 0) { al[k] += (gl_t)lo[0] * k8; ah[k] += (gl_t)hi[0] * k8; }   // MDS_MATRIX_DIAG[0] = 8
+        }
+        glx_acc_reduce3(al[0], ah[0], al[1], ah[1], al[2], ah[2], s[r0], s[r0 + 1], s[r0 + 2]);
+    }
+#else
 #pragma unroll
     for (int r = 0; r < 12; r++) {
         gl_t al = 0, ah = 0;   // each < (256 + 8 + 1) * 2^32 < 2^41
@@ -153,28 +191,30 @@ GL_HD void psd_mds_then_constants(gl_t (&s)[12], const gl_t* __restrict__ rc) {
             ah += (gl_t)hi[(i + r) % 12] * circ[i];
         }
         if (r == 0) { al += (gl_t)lo[0] * k8; ah += (gl_t)hi[0] * k8; }   // MDS_MATRIX_DIAG[0] = 8
-        // al + ah 2^32 as a 96-bit number, in 32-bit pieces so that no 64-bit register pair has to be rebuilt
-        const uint32_t al_hi = (uint32_t)(al >> 32), ah_lo = (uint32_t)ah;
-        const uint32_t mid = al_hi + ah_lo;
-        const uint32_t top = (uint32_t)(ah >> 32) + (mid < ah_lo ? 1u : 0u);
-        s[r] = gl_reduce96(((gl_t)mid << 32) | (uint32_t)al, top);
+        s[r] = psd_acc_reduce(al, ah);
     }
+#endif
 }
 // M[r][c] of the MDS matrix (circulant + diag(8, 0, ...)), compile-time after unrolling
 GL_HD constexpr uint32_t psd_mds_entry(int r, int c) {
     constexpr uint32_t circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     return circ[(c - r + 12) % 12] + ((r == 0 && c == 0) ? 8u : 0u);
 }
-// al + ah 2^32 (al, ah < 2^63) reduced to one word, in 32-bit pieces so that no 64-bit register pair has to be rebuilt
-GL_HD gl_t psd_acc_reduce(gl_t al, gl_t ah) {
-    const uint32_t al_hi = (uint32_t)(al >> 32), ah_lo = (uint32_t)ah;
-    const uint32_t mid = al_hi + ah_lo;
-    const uint32_t top = (uint32_t)(ah >> 32) + (mid < ah_lo ? 1u : 0u);
-    return gl_reduce96(((gl_t)mid << 32) | (uint32_t)al, top);
-}
 GL_HD void psd_sbox_all(gl_t (&s)[12]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // x^7 = (x * x^2) * x^4, three words at a time: glx_mul3 interleaves three independent products so that its carry chains
+    // need no wait states
 #pragma unroll
+    for (int k = 0; k < 12; k += 3) {
+        gl_t a2, b2, c2, a4, b4, c4, a3, b3, c3;
+        glx_mul3<false>(s[k], s[k], s[k + 1], s[k + 1], s[k + 2], s[k + 2], a2, b2, c2);
+        glx_mul3<false>(a2, a2, b2, b2, c2, c2, a4, b4, c4);
+        glx_mul3<false>(s[k], a2, s[k + 1], b2, s[k + 2], c2, a3, b3, c3);
+        glx_mul3<false>(a3, a4, b3, b4, c3, c4, s[k], s[k + 1], s[k + 2]);
+    }
+#else
     for (int i = 0; i < 12; i++) s[i] = psd_sbox(s[i]);
+#endif
 }
 #if defined(__HIPCC__)
 // Three partial rounds at once (tools/gen_poseidon_constants.py derive_groups): with d_j = sbox(x_j) - a_j the change of lane
@@ -221,14 +261,19 @@ __device__ __forceinline__ void psd_partial_group(gl_t (&s)[12], int g, const gl
     const gl_t d2 = gl_sub(psd_sbox(SUBST ? in[2] : a2), a2);
     const uint32_t d2l = (uint32_t)d2, d2h = (uint32_t)(d2 >> 32);
 #pragma unroll
-    for (int l = 0; l < 12; l++) {
-        al = (uint32_t)K[2 + l]; ah = K[2 + l] >> 32;
+    for (int l0 = 0; l0 < 12; l0 += 3) {
+        gl_t xl[3], xh[3];
 #pragma unroll
-        for (int i = 0; i < 12; i++) { const uint32_t c = M3[12 * l + i]; al += (gl_t)lo[i] * c; ah += (gl_t)hi[i] * c; }
-        { const uint32_t c = V2[l]; al += (gl_t)d0l * c; ah += (gl_t)d0h * c; }
-        { const uint32_t c = V1[l]; al += (gl_t)d1l * c; ah += (gl_t)d1h * c; }
-        { const uint32_t c = psd_mds_entry(l, 0); al += (gl_t)d2l * c; ah += (gl_t)d2h * c; }
-        s[l] = psd_acc_reduce(al, ah);
+        for (int k = 0; k < 3; k++) {
+            const int l = l0 + k;
+            xl[k] = (uint32_t)K[2 + l]; xh[k] = K[2 + l] >> 32;
+#pragma unroll
+            for (int i = 0; i < 12; i++) { const uint32_t c = M3[12 * l + i]; xl[k] += (gl_t)lo[i] * c; xh[k] += (gl_t)hi[i] * c; }
+            { const uint32_t c = V2[l]; xl[k] += (gl_t)d0l * c; xh[k] += (gl_t)d0h * c; }
+            { const uint32_t c = V1[l]; xl[k] += (gl_t)d1l * c; xh[k] += (gl_t)d1h * c; }
+            { const uint32_t c = psd_mds_entry(l, 0); xl[k] += (gl_t)d2l * c; xh[k] += (gl_t)d2h * c; }
+        }
+        glx_acc_reduce3(xl[0], xh[0], xl[1], xh[1], xl[2], xh[2], s[l0], s[l0 + 1], s[l0 + 2]);
     }
 }
 #endif
@@ -286,10 +331,7 @@ __device__ __forceinline__ gl_t psd_coop_permute(gl_t s, const int l) {
             al += (gl_t)lo_i * circ[i]; ah += (gl_t)hi_i * circ[i];
         }
         if (l == 0) { al += (gl_t)lo * 8; ah += (gl_t)hi * 8; }   // MDS_MATRIX_DIAG[0] = 8
-        const uint32_t al_hi = (uint32_t)(al >> 32), ah_lo = (uint32_t)ah;
-        const uint32_t mid = al_hi + ah_lo;
-        const uint32_t top = (uint32_t)(ah >> 32) + (mid < ah_lo ? 1u : 0u);
-        s = gl_reduce96(((gl_t)mid << 32) | (uint32_t)al, top);
+        s = psd_acc_reduce(al, ah);
         if (l >= 12) s = 0;
     }
     return s;
