@@ -1,4 +1,4 @@
-// Goldilocks products for gfx950, three at a time (device only).
+// Goldilocks arithmetic hand-scheduled for gfx950 (device only): products three at a time, canonical add / subtract / shift.
 //
 // What the instruction stream costs on this chip (tools/ubench/valu_class.hip, valu_mix.hip, gl_prims.hip; profiles/README.md):
 // the 64-bit / multiply / compare instructions (v_mad_u64_u32, v_lshl_add_u64, v_cmp_*, v_lshlrev_b32 ...) take ~4.2 cycles of the
@@ -255,6 +255,104 @@ __device__ __forceinline__ void glx_acc_reduce3(gl_t alA, gl_t ahA, gl_t alB, gl
         : [tA] "v"(topA), [loA] "v"(loA), [tB] "v"(topB), [loB] "v"(loB), [tC] "v"(topC), [loC] "v"(loC));
     rA = zA + (gl_t)eA; rB = zB + (gl_t)eB; rC = zC + (gl_t)eC;
 }
+
+// ---- canonical arithmetic for the NTT butterflies: operands < p in, results < p out (one fix-up each instead of two) ----------
+__device__ __forceinline__ gl_t glx_canon(gl_t x) { return x + ((x >= GL_P) ? GL_EPS : 0); }          // x - p mod 2^64
+__device__ __forceinline__ gl_t glx_add_cc(gl_t a, gl_t b) {                                             // 5 instructions
+    const gl_t s = a + b;
+    return s + (((s < a) | (s >= GL_P)) ? GL_EPS : 0);
+}
+__device__ __forceinline__ gl_t glx_sub_cc(gl_t a, gl_t b) {                                             // 5 instructions
+#ifdef GLX_C_BUTTERFLY
+    const gl_t d = a - b;
+    return d - ((a < b) ? GL_EPS : 0);
+#endif
+    uint32_t r0 = (uint32_t)a, r1 = (uint32_t)(a >> 32), e;
+    asm("v_sub_co_u32 %[r0], vcc, %[r0], %[b0]\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32 %[r1], vcc, %[r1], %[b1], vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"                        // borrow: + p = - EPS (mod 2^64)
+        "v_sub_co_u32 %[r0], vcc, %[r0], %[e]\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc"
+        : [r0] "+v"(r0), [r1] "+v"(r1), [e] "=&v"(e)
+        : [b0] "v"((uint32_t)b), [b1] "v"((uint32_t)(b >> 32))
+        : "vcc");
+    return glx_mk64(r0, r1);
+}
+// z (+ carry mask c) -> canonical: add EPS (= subtract p mod 2^64) when the carry is set or z >= p
+__device__ __forceinline__ gl_t glx_fix_canon(gl_t z, uint64_t c) {
+    uint32_t e; uint64_t ge;
+    asm("s_nop 0\n\t"
+        "v_cmp_gt_u64_e64 %[ge], %[z], %[pm1]\n\t"
+        "s_nop 1\n\t"
+        "s_or_b64 %[ge], %[ge], %[c]\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, %[ge]"
+        : [e] "=v"(e), [ge] "=&s"(ge) : [z] "v"(z), [pm1] "s"(GL_P - 1), [c] "s"(c) : "scc");
+    return z + (gl_t)e;
+}
+// canonical x times 2^E (0 < E < 96), canonical result: the butterfly twiddles (the reference's w_64 = 2^39, 2^96 = -1)
+template <int E>
+__device__ __forceinline__ gl_t glx_shl_c(gl_t x) {
+    static_assert(E > 0 && E < 96, "shift twiddle exponent");
+#ifdef GLX_C_BUTTERFLY
+    if constexpr (E < 32) {
+        const gl_t ml = x << E;
+        const gl_t t = (gl_t)((uint32_t)(x >> 32) >> (32 - E)) * 0xFFFFFFFFu;
+        const gl_t zz = ml + t;
+        return zz + (((zz < t) | (zz >= GL_P)) ? GL_EPS : 0);
+    } else if constexpr (E >= 64) {
+        constexpr int R = E - 64;
+        const gl_t le = (gl_t)((uint32_t)x << R) * 0xFFFFFFFFu, hm = x >> (32 - R);
+        const gl_t d = le - hm;
+        return d - ((le < hm) ? GL_EPS : 0);
+    }
+#endif
+    gl_t z; uint64_t c;
+    if constexpr (E < 32) {                     // (h:m:l) = x << E: (m:l) + h EPS < 2^64 + 2^63
+        const gl_t ml = x << E;
+        const uint32_t h = (uint32_t)(x >> 32) >> (32 - E);
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"(h), "v"(ml));
+        return glx_fix_canon(z, c);
+    } else if constexpr (E == 32) {             // x0 2^32 + x1 2^64 = (x0 << 32) + x1 EPS, both canonical
+        const gl_t a = x << 32;
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"((uint32_t)(x >> 32)), "v"(a));
+        return glx_fix_canon(z, c);
+    } else if constexpr (E < 64) {              // x 2^E = a + m EPS - h: a = low 64 bits of x << E (= l 2^32 <= p - 1), (h:m) = x >> (64 - E)
+        const gl_t a = x << E, u = x >> (64 - E);
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"((uint32_t)u), "v"(a));
+        // y = z - h mod 2^64, borrow b; true value y + (c - b) 2^64 in (-2^31, 2^65): c > b: + EPS, b > c: - EPS, both then < p; else y may be >= p
+        uint32_t y0 = (uint32_t)z, y1 = (uint32_t)(z >> 32), f0, f1;
+        uint64_t bw, t, g;
+        asm("s_nop 0\n\t"
+            "v_sub_co_u32 %[y0], vcc, %[y0], %[h]\n\t"
+            "s_nop 1\n\t"
+            "v_subbrev_co_u32_e64 %[y1], %[bw], 0, %[y1], vcc"
+            : [y0] "+v"(y0), [y1] "+v"(y1), [bw] "=&s"(bw) : [h] "v"((uint32_t)(u >> 32)) : "vcc");
+        const gl_t y = glx_mk64(y0, y1);
+        asm("v_cmp_gt_u64_e64 %[g], %[y], %[pm1]\n\t"
+            "s_andn2_b64 %[t], %[bw], %[c]\n\t"
+            "s_andn2_b64 %[bw], %[c], %[bw]\n\t"
+            "s_nop 0\n\t"
+            "s_andn2_b64 %[g], %[g], %[t]\n\t"
+            "s_or_b64 %[bw], %[g], %[bw]\n\t"
+            "v_cndmask_b32_e64 %[f1], 0, -1, %[t]\n\t"
+            "v_cndmask_b32_e64 %[f0], 0, -1, %[bw]\n\t"
+            "v_sub_u32 %[f0], %[f0], %[f1]"
+            : [f0] "=&v"(f0), [f1] "=&v"(f1), [t] "=&s"(t), [g] "=&s"(g), [bw] "+s"(bw)
+            : [y] "v"(y), [pm1] "s"(GL_P - 1), [c] "s"(c)
+            : "scc");
+        return y + glx_mk64(f0, f1);
+    } else {                                    // (h:m:l) = x << (E - 64): l EPS - (h:m), both canonical
+        constexpr int R = E - 64;
+        const uint32_t l = (uint32_t)x << R;
+        const gl_t hm = x >> (32 - R);
+        gl_t le;
+        asm("v_mad_u64_u32 %0, vcc, %1, -1, 0" : "=v"(le) : "v"(l) : "vcc");
+        return glx_sub_cc(le, hm);
+    }
+}
 #elif defined(__HIPCC__)
 // host pass of a .hip file: kernels that call these must still parse
 template <bool CANON>
@@ -262,6 +360,11 @@ __device__ void glx_mul3(gl_t aA, gl_t bA, gl_t aB, gl_t bB, gl_t aC, gl_t bC, g
 template <bool CANON>
 __device__ gl_t glx_mul(gl_t a, gl_t b);
 __device__ gl_t glx_reduce96(gl_t lo, uint32_t top);
+__device__ gl_t glx_canon(gl_t x);
+__device__ gl_t glx_add_cc(gl_t a, gl_t b);
+__device__ gl_t glx_sub_cc(gl_t a, gl_t b);
+template <int E>
+__device__ gl_t glx_shl_c(gl_t x);
 __device__ gl_t glx_acc_reduce(gl_t al, gl_t ah);
 __device__ void glx_acc_reduce3(gl_t alA, gl_t ahA, gl_t alB, gl_t ahB, gl_t alC, gl_t ahC, gl_t& rA, gl_t& rB, gl_t& rC);
 #endif

@@ -13,8 +13,14 @@
 //                      multiply by w_N^(i2*k1), store Y[k1*N2+i2]             (same footprint it read)
 //   pass B ("row"):    for T adjacent rows k1: FFT over i2, store X[k1 + N1*k2] (T-element segments)
 //   N <= 2^12:         a single row pass with N1 = 1 over T polynomials of the batch.
+//
+// Inside a pass every value is kept CANONICAL (< p): inputs are canonicalised when loaded, and add / subtract / shift-twiddle /
+// multiply each return the canonical representative with ONE fix-up (gl64_gfx950.cuh: 5 instructions for an add or a subtract
+// instead of 7 / 10 with two fix-ups, 6-11 for a shift twiddle instead of 8-26; general multiplies three at a time).  The stores
+// need no final canonicalisation.
 #pragma once
 #include "gl64.cuh"
+#include "gl64_gfx950.cuh"
 
 #define NTT_TILE_LOG 13                 // elements per workgroup tile (8192 * 8 B = 64 KiB of LDS)
 #define NTT_THREADS 512
@@ -55,32 +61,54 @@ __host__ __device__ constexpr unsigned ntt_bitrev(unsigned x, int bits) {
     return r;
 }
 
-// In-register DFT of R = 2^LOGR points (decimation in frequency); X[q] is left in u[bitrev(q)].
+// x * 2^e for a compile-time e in [0, 96), canonical in and out
+template <unsigned E>
+__device__ __forceinline__ gl_t ntt_shift_twiddle(gl_t x) {
+    if constexpr (E == 0) return x;
+    else return glx_shl_c<(int)E>(x);
+}
+template <int LOGR, bool INV, int LG, int B, int I>
+__device__ __forceinline__ void ntt_small_dft_bfly(gl_t* u) {
+    constexpr int s = 1 << (LG - 1);
+    // w_{2s}^i = 2^(39 * (32/s) * i); 2^96 = -1, so a twiddle -2^k is applied as (c - a) * 2^k: no negation
+    constexpr unsigned e0 = (39u * (32u / (unsigned)s) * (unsigned)I) % 192u;
+    constexpr unsigned e = INV ? (192u - e0) % 192u : e0;
+    const gl_t a = u[B + I], c = u[B + I + s];
+    u[B + I] = glx_add_cc(a, c);
+    const gl_t d = (e >= 96u) ? glx_sub_cc(c, a) : glx_sub_cc(a, c);
+    u[B + I + s] = ntt_shift_twiddle<e % 96u>(d);
+}
+template <int LOGR, bool INV, int LG, int B, int I>
+__device__ __forceinline__ void ntt_small_dft_i(gl_t* u) {
+    constexpr int s = 1 << (LG - 1);
+    if constexpr (I < s) { ntt_small_dft_bfly<LOGR, INV, LG, B, I>(u); ntt_small_dft_i<LOGR, INV, LG, B, I + 1>(u); }
+}
+template <int LOGR, bool INV, int LG, int B>
+__device__ __forceinline__ void ntt_small_dft_b(gl_t* u) {
+    constexpr int R = 1 << LOGR, s = 1 << (LG - 1);
+    if constexpr (B < R) { ntt_small_dft_i<LOGR, INV, LG, B, 0>(u); ntt_small_dft_b<LOGR, INV, LG, B + 2 * s>(u); }
+}
+template <int LOGR, bool INV, int LG>
+__device__ __forceinline__ void ntt_small_dft_l(gl_t* u) {
+    if constexpr (LG >= 1) { ntt_small_dft_b<LOGR, INV, LG, 0>(u); ntt_small_dft_l<LOGR, INV, LG - 1>(u); }
+}
+// In-register DFT of R = 2^LOGR points (decimation in frequency) on canonical values; X[q] is left in u[bitrev(q)].
 template <int LOGR, bool INV>
-__device__ __forceinline__ void ntt_small_dft(gl_t* u) {
-    constexpr int R = 1 << LOGR;
+__device__ __forceinline__ void ntt_small_dft(gl_t* u) { ntt_small_dft_l<LOGR, INV, LOGR>(u); }
+
+// v[k] *= tw[k] for k < COUNT, canonical results: products go three at a time (glx_mul3)
+template <int COUNT>
+__device__ __forceinline__ void ntt_mul_many(gl_t* v, const gl_t* tw) {
+    constexpr int G = COUNT / 3 * 3;
 #pragma unroll
-    for (int lg = LOGR; lg >= 1; lg--) {
-        const int s = 1 << (lg - 1);
+    for (int k = 0; k < G; k += 3) glx_mul3<true>(v[k], tw[k], v[k + 1], tw[k + 1], v[k + 2], tw[k + 2], v[k], v[k + 1], v[k + 2]);
 #pragma unroll
-        for (int b = 0; b < R; b += 2 * s) {
-#pragma unroll
-            for (int i = 0; i < s; i++) {
-                gl_t a = u[b + i], c = u[b + i + s];
-                u[b + i] = gl_add(a, c);
-                // w_{2s}^i = 2^(39 * (32/s) * i); 2^96 = -1, so a twiddle -2^k is applied as (c - a) * 2^k: no negation
-                unsigned e = (39u * (32u / (unsigned)s) * (unsigned)i) % 192u;
-                if (INV) e = (192u - e) % 192u;
-                const gl_t d = (e >= 96u) ? gl_sub(c, a) : gl_sub(a, c);
-                u[b + i + s] = gl_mul_2exp(d, e % 96u);
-            }
-        }
-    }
+    for (int k = G; k < COUNT; k++) v[k] = glx_mul<true>(v[k], tw[k]);
 }
 
 __device__ __forceinline__ gl_t ntt_pow2level(const gl_t* lo, const gl_t* hi, uint32_t e) {
     // hi[0] carries the table's scale factor, so the high part is always applied
-    return gl_mul(lo[e & ((1u << NTT_SPLIT_LOG) - 1)], hi[e >> NTT_SPLIT_LOG]);
+    return glx_mul<true>(lo[e & ((1u << NTT_SPLIT_LOG) - 1)], hi[e >> NTT_SPLIT_LOG]);
 }
 
 // ---- LDS tile layout --------------------------------------------------------------------------------
@@ -110,6 +138,22 @@ __device__ __forceinline__ void ntt_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// zero-padded first stage (radix 16 or 8): output o of the task is x0 + w_R^o x1 (radix 8: x0), canonical
+template <int R, bool INV, int O>
+__device__ __forceinline__ void ntt_zp_first_all(gl_t x0, gl_t x1, gl_t* out) {
+    if constexpr (O < R) {
+        if constexpr (R != 16) out[O] = x0;
+        else if constexpr (O == 0) out[O] = glx_add_cc(x0, x1);
+        else {              // w_16^o = 2^(156 o) (the reference's w_64 = 2^39); 2^96 = -1
+            constexpr unsigned e0 = (156u * (unsigned)O) % 192u;
+            constexpr unsigned e = INV ? (192u - e0) % 192u : e0;
+            const gl_t tt = ntt_shift_twiddle<e % 96u>(x1);
+            out[O] = (e >= 96u) ? glx_sub_cc(x0, tt) : glx_add_cc(x0, tt);
+        }
+        ntt_zp_first_all<R, INV, O + 1>(x0, x1, out);
+    }
 }
 
 // All Stockham stages over the tile in LDS: L = 2^LOGL points per column, Ns = 2^LOGNS already combined.
@@ -150,19 +194,10 @@ __device__ __forceinline__ void ntt_lds_stages(gl_t* lds, const gl_t* __restrict
 #pragma unroll
             for (int q = 0; q < TPT; q++) {
                 const int j0 = tj[q] << LOGR;
+                gl_t outv[R];
+                ntt_zp_first_all<R, INV, 0>(u[q][0], u[q][1], outv);
 #pragma unroll
-                for (int o = 0; o < R; o++) {
-                    gl_t v = u[q][0];
-                    if constexpr (R == 16) {
-                        if (o) {            // w_16^o = 2^(156 o) (the reference's w_64 = 2^39); 2^96 = -1
-                            unsigned e = (156u * (unsigned)o) % 192u;
-                            if (INV) e = (192u - e) % 192u;
-                            const gl_t tt = gl_mul_2exp(u[q][1], e % 96u);
-                            v = (e >= 96u) ? gl_sub(v, tt) : gl_add(v, tt);
-                        } else v = gl_add(v, u[q][1]);
-                    }
-                    lds[G::at(tcol[q], j0 + o)] = v;
-                }
+                for (int o = 0; o < R; o++) lds[G::at(tcol[q], j0 + o)] = outv[o];
             }
         } else
 #pragma unroll
@@ -170,9 +205,10 @@ __device__ __forceinline__ void ntt_lds_stages(gl_t* lds, const gl_t* __restrict
             const int j = tj[q];
             const int k = j & (NS - 1);
             if constexpr (LOGNS > 0) {
+                gl_t tw[R - 1];
 #pragma unroll
-                for (int r = 1; r < R; r++)
-                    u[q][r] = gl_mul(u[q][r], tw_local[(r * k) << (NTT_LOCAL_MAX_LOG - LOGNS - LOGR)]);
+                for (int r = 1; r < R; r++) tw[r - 1] = tw_local[(r * k) << (NTT_LOCAL_MAX_LOG - LOGNS - LOGR)];
+                ntt_mul_many<R - 1>(&u[q][1], tw);
             }
             ntt_small_dft<LOGR, INV>(u[q]);
             const int j0 = ((j - k) << LOGR) + k;
@@ -215,22 +251,38 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_col_pass(NttPassParams p) {
         const int e = tid + NTT_THREADS * q;
         const uint32_t t = e & (T - 1), i1 = e >> LOGT;
         const uint32_t i = (i1 << lgN2) + c0 + t;
-        gl_t x = v[q];
-        if (p.pre_lo && i < p.n_in) x = gl_mul(x, ntt_pow2level(p.pre_lo, p.pre_hi, i));
+        gl_t x;
+        if (p.pre_lo && i < p.n_in) x = glx_mul<true>(v[q], ntt_pow2level(p.pre_lo, p.pre_hi, i));
+        else x = glx_canon(v[q]);             // the caller's values may be any u64 representatives
         lds[G::at(t, i1)] = x;
     }
     __syncthreads();
     if (!NTT_DBG(p, 1)) ntt_lds_stages<LOGL, 0, INV, ZP>(lds, p.tw_local, tid);
     if constexpr (G::WAVE_OWNED) __syncthreads();
-    // store with the inter-pass twiddle w_N^(i2*k1)
-#pragma unroll 4
-    for (int q = 0; q < NTT_EPT; q++) {
+    // store with the inter-pass twiddle w_N^(i2*k1); the products go three at a time
+    auto elem = [&](int q, gl_t& x, gl_t& tw, uint64_t& o) {
         const int e = tid + NTT_THREADS * q;
         const uint32_t t = e & (T - 1), k1 = e >> LOGT;
         const uint32_t i2 = c0 + t;
-        gl_t x = lds[G::at(t, k1)];
-        const uint64_t o = ((uint64_t)k1 << lgN2) + i2;
-        x = gl_mul(x, p.tw_pass ? p.tw_pass[o] : ntt_pow2level(p.tw_lo, p.tw_hi, i2 * k1));
+        x = lds[G::at(t, k1)];
+        o = ((uint64_t)k1 << lgN2) + i2;
+        tw = p.tw_pass ? p.tw_pass[o] : ntt_pow2level(p.tw_lo, p.tw_hi, i2 * k1);
+    };
+    constexpr int QG = NTT_EPT / 3 * 3;
+#pragma unroll 2
+    for (int q = 0; q < QG; q += 3) {
+        gl_t x[3], tw[3]; uint64_t o[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) elem(q + k, x[k], tw[k], o[k]);
+        glx_mul3<true>(x[0], tw[0], x[1], tw[1], x[2], tw[2], x[0], x[1], x[2]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (!NTT_DBG(p, 4) || x[k] == 12345) dst[o[k]] = x[k];
+    }
+#pragma unroll
+    for (int q = QG; q < NTT_EPT; q++) {
+        gl_t x, tw; uint64_t o;
+        elem(q, x, tw, o);
+        x = glx_mul<true>(x, tw);
         if (!NTT_DBG(p, 4) || x == 12345) dst[o] = x;
     }
 }
@@ -269,7 +321,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_row_pass(NttPassParams p) {
         const int e = tid + NTT_THREADS * q;
         const uint32_t i2 = e & (L - 1), r = e >> LOGL;
         gl_t x = v[q];
-        if (single && p.pre_lo && i2 < p.n_in) x = gl_mul(x, ntt_pow2level(p.pre_lo, p.pre_hi, i2));
+        if (single) {       // two-pass: the column pass left canonical values
+            if (p.pre_lo && i2 < p.n_in) x = glx_mul<true>(x, ntt_pow2level(p.pre_lo, p.pre_hi, i2));
+            else x = glx_canon(x);
+        }
         lds[G::at(r, i2)] = x;
     }
     __syncthreads();
@@ -284,9 +339,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_row_pass(NttPassParams p) {
             const uint32_t poly = r0 + r;
             if (poly < p.batch) {
                 gl_t x = lds[G::at(r, k)];
-                if (p.post_lo) x = gl_mul(x, ntt_pow2level(p.post_lo, p.post_hi, k));
-                else if (p.post_const != 1) x = gl_mul(x, p.post_const);
-                p.dst[(uint64_t)poly * p.dst_stride + k] = gl_canon(x);
+                if (p.post_lo) x = glx_mul<true>(x, ntt_pow2level(p.post_lo, p.post_hi, k));
+                else if (p.post_const != 1) x = glx_mul<true>(x, p.post_const);
+                p.dst[(uint64_t)poly * p.dst_stride + k] = x;
             }
         }
     } else {
@@ -298,9 +353,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_row_pass(NttPassParams p) {
             const uint32_t r = e & (T - 1), k2 = e >> LOGT;
             const uint32_t k = (r0 + r) + (k2 << lgN1);
             gl_t x = lds[G::at(r, k2)];
-            if (p.post_lo) x = gl_mul(x, ntt_pow2level(p.post_lo, p.post_hi, k));
-            else if (p.post_const != 1) x = gl_mul(x, p.post_const);
-            if (!NTT_DBG(p, 4) || x == 12345) dst[k] = gl_canon(x);
+            if (p.post_lo) x = glx_mul<true>(x, ntt_pow2level(p.post_lo, p.post_hi, k));
+            else if (p.post_const != 1) x = glx_mul<true>(x, p.post_const);
+            if (!NTT_DBG(p, 4) || x == 12345) dst[k] = x;
         }
     }
 }

@@ -12,7 +12,7 @@
 #pragma once
 #include <stdlib.h>
 #include "gl64.cuh"
-#include "gl64_mul3.cuh"
+#include "gl64_gfx950.cuh"
 #include "poseidon_constants.h"
 
 #if defined(__HIPCC__)

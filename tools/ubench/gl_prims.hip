@@ -8,7 +8,7 @@
 #include <stdio.h>
 #include <vector>
 #include "gl64.cuh"
-#include "gl64_mul3.cuh"
+#include "gl64_gfx950.cuh"
 
 typedef uint32_t u32;
 #define ITERS 512
@@ -204,44 +204,6 @@ __device__ __forceinline__ gl_t m_fix_canon(gl_t z, uint64_t c) {
         : [e] "=v"(e), [ge] "=&s"(ge) : [z] "v"(z), [pm1] "s"(GL_P - 1), [c] "s"(c) : "scc");
     return z + (gl_t)e;
 }
-// canonical x times 2^E, canonical result, for the butterfly twiddles (E a compile-time constant in (0, 96))
-template <int E>
-__device__ __forceinline__ gl_t m_shl_c(gl_t x) {
-    gl_t z; uint64_t c;
-    if constexpr (E < 32) {                     // (h:m:l) = x << E: (m:l) + h * EPS
-        const gl_t ml = x << E;
-        const u32 h = (u32)(x >> 32) >> (32 - E);
-        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"(h), "v"(ml));
-        return m_fix_canon(z, c);
-    } else if constexpr (E == 32) {             // x0 2^32 + x1 2^64 = (x0 << 32) + x1 * EPS: both canonical
-        const gl_t a = x << 32;
-        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"((u32)(x >> 32)), "v"(a));
-        return m_fix_canon(z, c);
-    } else if constexpr (E < 64) {              // x 2^E = A + m EPS - h with A = low 64 bits of x << E = l 2^32, (h:m) = x >> (64 - E)
-        const gl_t a = x << E, u = x >> (64 - E);
-        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"((u32)u), "v"(a));
-        // T = a + m EPS - h >= 0 always (l = m = 0 implies h = 0; otherwise a + m EPS >= 2^32 - 1 >= h), so after y = z - h (borrow b)
-        // the cases are (c, b) = (0,0): y, (1,0): y + EPS, (1,1): y; and y + EPS < p in the second; in the others y may be >= p
-        u32 y0 = (u32)z, y1 = (u32)(z >> 32);
-        uint64_t mk;
-        asm("s_nop 0\n\t"
-            "v_sub_co_u32 %[y0], vcc, %[y0], %[h]\n\t"
-            "s_nop 1\n\t"
-            "v_subbrev_co_u32 %[y1], vcc, 0, %[y1], vcc\n\t"
-            "s_nop 1\n\t"
-            "s_andn2_b64 %[mk], %[c], vcc"
-            : [y0] "+v"(y0), [y1] "+v"(y1), [mk] "=&s"(mk) : [h] "v"((u32)(u >> 32)), [c] "s"(c) : "vcc", "scc");
-        return m_fix_canon(mk64(y0, y1), mk);
-    } else {                                    // (h:m:l) = x << (E - 64): l EPS - (h:m), both canonical
-        constexpr int R = E - 64;
-        const u32 l = (u32)x << R;
-        const gl_t hm = x >> (32 - R);
-        gl_t le;
-        asm("v_mad_u64_u32 %0, vcc, %1, -1, 0" : "=v"(le) : "v"(l) : "vcc");
-        return m_sub_cc(le, hm);
-    }
-}
-
 // MDS accumulator pair -> field element (al, ah < 2^63): candidates for psd_acc_reduce
 __device__ __forceinline__ gl_t c_accred_compiler(gl_t al, gl_t ah) {
     const u32 al_hi = (u32)(al >> 32), ah_lo = (u32)ah;
@@ -360,7 +322,7 @@ __global__ __launch_bounds__(256) void k_chain_sbox12(const gl_t* in, gl_t* out)
 FN2(c_mul_compiler); FN2(m_mul); FN2(m_mul_c); FN2(m_add_cc); FN2(m_sub_cc); FN2(m_accred); FN2(c_add_compiler); FN2(a_add); FN2(c_sub_compiler); FN2(a_sub);
 FN2(c_addc_compiler); FN2(a_add_c); FN2(c_accred_compiler);
 FN1(c12, c_shl_compiler<12>); FN1(c24, c_shl_compiler<24>); 
-FN1(m12, m_shl_c<12>); FN1(m24, m_shl_c<24>); FN1(m32, m_shl_c<32>); FN1(m36, m_shl_c<36>); FN1(m48, m_shl_c<48>); FN1(m60, m_shl_c<60>); FN1(m72, m_shl_c<72>); FN1(m84, m_shl_c<84>); FN1(c72, c_shl_compiler<72>);
+FN1(m12, glx_shl_c<12>); FN1(m24, glx_shl_c<24>); FN1(m32, glx_shl_c<32>); FN1(m36, glx_shl_c<36>); FN1(m48, glx_shl_c<48>); FN1(m60, glx_shl_c<60>); FN1(m72, glx_shl_c<72>); FN1(m84, glx_shl_c<84>); FN1(c72, c_shl_compiler<72>);
 FN1(c36, c_shl_compiler<36>); FN1(c60, c_shl_compiler<60>); FN1(c84, c_shl_compiler<84>); FN1(c48, c_shl_compiler<48>);
 
 static const uint64_t P = 0xFFFFFFFF00000001ULL;
