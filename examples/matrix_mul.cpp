@@ -28,6 +28,9 @@ int main(int argc, char** argv) {
     const uint64_t seed_arg = argc > 2 ? (uint64_t)strtoull(argv[2], nullptr, 10) : 0;
     std::mt19937_64 rng(seed_arg ? seed_arg : ((uint64_t)std::random_device{}() << 32) ^ std::random_device{}());
     const size_t batch = argc > 3 ? (size_t)atoi(argv[3]) : 1;
+    // the batch mode keeps several proofs in flight on as many HIP streams; HIP multiplexes streams onto GPU_MAX_HW_QUEUES
+    // hardware queues (default 4), so give every stream its own before the runtime initialises
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
 
     // ---- build (matrix_mul.rs:25-67): circuit description on the host, constants/sigmas commitment on the GPU ----
     auto t0 = std::chrono::steady_clock::now();

@@ -247,7 +247,7 @@ extern "C" void gl_ctx_destroy(gl_ctx* c) {
 extern "C" int gl_ctx_synchronize(gl_ctx* c) {
     GL_REQUIRE(c, GL_ERR_ARG, "null ctx");
     GL_TRY(c->activate());
-    GL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    GL_CHECK_HIP(gl_stream_wait(c->stream));
     return GL_OK;
 }
 extern "C" int gl_ctx_set_scratch_elems(gl_ctx* c, size_t elems) {
@@ -280,7 +280,7 @@ extern "C" int gl_copy_d2h(gl_ctx* c, void* h_dst, const void* d_src, size_t byt
     GL_REQUIRE(c && h_dst && d_src, GL_ERR_ARG, "null argument");
     GL_TRY(c->activate());
     GL_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
-    GL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    GL_CHECK_HIP(gl_stream_wait(c->stream));
     return GL_OK;
 }
 

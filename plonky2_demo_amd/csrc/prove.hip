@@ -803,7 +803,7 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     cv.push_back(zeta.a); cv.push_back(zeta.b); cv.push_back(fri_alpha[0]); cv.push_back(fri_alpha[1]); cv.push_back(pow_witness);
     for (int i = 0; i < 4; i++) cv.push_back(pi_hash[i]);
     cv.insert(cv.end(), fri_betas.begin(), fri_betas.end());
-    GL_CHECK_HIP(hipStreamSynchronize(st));
+    GL_CHECK_HIP(gl_stream_wait(st));
     *out = proof.release();
     return GL_OK;
 }
