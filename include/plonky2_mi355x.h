@@ -317,6 +317,23 @@ int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_sigmas_cap,
 int gl_host_circuit_verify(const gl_host_circuit* hc, const uint64_t* constants_sigmas_cap, const uint64_t circuit_digest[4],
                            const uint8_t* proof_bytes, size_t num_bytes);
 
+/* ---- circuit data as bytes --------------------------------------------------------------------------*/
+/* The reference's serialised forms (plonky2/src/plonk/circuit_data.rs:125-142,208-238; util/serialization/mod.rs:739-800,
+ * 1736-1790 CommonCircuitData, :909-930,1889-1906 VerifierOnlyCircuitData, :1908-1919 VerifierCircuitData = verifier_only ||
+ * common; gates tagged as by DefaultGateSerializer, util/serialization/gate_serialization.rs:87-108), so that a Rust-built
+ * circuit's CommonCircuitData / VerifierCircuitData bytes can be handed over instead of a hand-filled gl_circuit_desc.  Host code.
+ * Representable: the demo's five gates, standard_recursion_config's shape (no lookups, no zero-knowledge); anything else
+ * is GL_ERR_UNSUPPORTED when reading.  h_out may be null to query *num_bytes.  The value columns (constants, sigmas) and the
+ * generators of ProverOnlyCircuitData are not part of these forms: gl_circuit_create still takes the columns. */
+int gl_common_data_to_bytes(const gl_circuit_desc* desc, uint8_t* h_out, size_t cap, size_t* num_bytes);
+int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_bytes, gl_circuit_desc* out, size_t* consumed /* may be null */);
+int gl_verifier_only_to_bytes(uint32_t cap_height, const uint64_t* constants_sigmas_cap, const uint64_t circuit_digest[4], uint8_t* h_out,
+                              size_t cap, size_t* num_bytes);
+int gl_verifier_only_from_bytes(const uint8_t* h_bytes, size_t num_bytes, uint32_t* cap_height, uint64_t* h_cap /* [2^h][4], may be null */,
+                                size_t cap_words, uint64_t circuit_digest[4], size_t* consumed /* may be null */);
+/* VerifierCircuitData::from_bytes(data).verify(proof): GL_OK = accepted, GL_ERR_VERIFY = rejected (as gl_verify) */
+int gl_verify_bytes(const uint8_t* h_verifier_data, size_t num_data_bytes, const uint8_t* proof_bytes, size_t num_proof_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -229,6 +229,61 @@ int orc_verify_bytes(const void* c, const u64* cap, const u64* digest, const uin
     return m ? 1 : 0;
 }
 const char* orc_verify_bytes_message(void) { return g_verify_msg2; }
+
+// ---- CommonCircuitData::to_bytes / VerifierCircuitData::to_bytes restated from the oracle's own CommonData --------------------
+// (util/serialization/mod.rs:1596-1790,1889-1919; gate tags gate_serialization.rs:89-107; gates/arithmetic_base.rs:63-65,
+// gates/constant.rs:49-51).  A second, independent writer: tests demand that the product's bytes are identical.
+namespace {
+struct ByteSink {
+    std::vector<uint8_t> b;
+    void usize(u64 x) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(x >> (8 * i))); }
+    void word32(uint32_t x) { for (int i = 0; i < 4; i++) b.push_back((uint8_t)(x >> (8 * i))); }
+    void byte(uint8_t x) { b.push_back(x); }
+};
+static void sink_fri_config(ByteSink& o, const CircuitConfig& c) {
+    o.usize(c.rate_bits); o.usize(c.cap_height); o.usize(c.num_query_rounds); o.word32(c.proof_of_work_bits);
+    o.byte(1); o.usize(c.fri_arity_bits); o.usize(c.fri_final_poly_bits);                  // ConstantArityBits
+}
+static void sink_common(ByteSink& o, const CommonData& cm) {
+    const CircuitConfig& c = cm.config;
+    o.usize(c.num_wires); o.usize(c.num_routed_wires); o.usize(c.num_constants); o.usize(100 /* security_bits, circuit_data.rs:77 */); o.usize(c.num_challenges);
+    o.usize(c.max_quotient_degree_factor); o.byte(1); o.byte(0);
+    sink_fri_config(o, c);
+    sink_fri_config(o, c);                                                                 // FriParams.config
+    o.usize(cm.fri_reduction_arity_bits.size()); for (auto a : cm.fri_reduction_arity_bits) o.usize(a);
+    o.usize(cm.degree_bits); o.byte(0);
+    o.usize(cm.selectors.gates.size());
+    for (GateType g : cm.selectors.gates) {
+        switch (g) {
+            case GATE_ARITHMETIC: o.word32(0); o.usize(c.num_routed_wires / 4); break;     // ArithmeticGate::new_from_config: num_ops = routed / 4
+            case GATE_CONSTANT: o.word32(3); o.usize(c.num_constants); break;
+            case GATE_NOOP: o.word32(9); break;
+            case GATE_POSEIDON: o.word32(11); break;
+            default: o.word32(12); break;                                                  // PublicInputGate
+        }
+    }
+    o.usize(cm.selectors.selector_indices.size()); for (auto i : cm.selectors.selector_indices) o.usize(i);
+    o.usize(cm.selectors.groups.size()); for (auto& g : cm.selectors.groups) { o.usize(g.first); o.usize(g.second); }
+    o.usize(cm.quotient_degree_factor); o.usize(cm.num_gate_constraints); o.usize(cm.num_constants); o.usize(cm.num_public_inputs);
+    o.usize(cm.k_is.size()); for (auto k : cm.k_is) o.usize(canon(k));
+    o.usize(cm.num_partial_products);
+    o.usize(0); o.usize(0); o.usize(0);
+}
+}
+// kind 0: CommonCircuitData, kind 1: VerifierCircuitData (verifier_only || common).  Returns the size; writes when cap suffices.
+size_t orc_circuit_data_bytes(const void* c, int kind, uint8_t* out, size_t cap) {
+    const CircuitData* cd = (const CircuitData*)c;
+    ByteSink o;
+    if (kind == 1) {
+        auto capv = cd->constants_sigmas_commitment.tree.cap();
+        o.usize(cd->common.config.cap_height);
+        for (auto& d : capv) for (int i = 0; i < 4; i++) o.usize(canon(d.e[i]));
+        for (int i = 0; i < 4; i++) o.usize(canon(cd->circuit_digest.e[i]));
+    }
+    sink_common(o, cd->common);
+    if (out && cap >= o.b.size()) memcpy(out, o.b.data(), o.b.size());
+    return o.b.size();
+}
 void orc_circuit_free(void* c) { delete (CircuitData*)c; }
 // out: [degree_bits, num_constants, num_gate_constraints, num_partial_products, num_public_inputs, num_selectors,
 //       num_fri_rounds, final_poly_len, pi_row, constant_row, num_arith_ops, num_poseidon_rows]

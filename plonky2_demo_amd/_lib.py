@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplonky2_mi355x.so")
+# PLONKY2_MI355X_LIB: another build of the same library (e.g. the -DNTT_ABLATION diagnostic build of tools/ablation.sh)
+LIB_PATH = os.environ.get("PLONKY2_MI355X_LIB") or os.path.join(_HERE, "libplonky2_mi355x.so")
 
 GL_OK = 0
 GL_ERR_VERIFY = 6
@@ -130,6 +131,11 @@ SIGNATURES = {
     "gl_proof_free": (None, [c_vp]),
     "gl_verify": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz]),
     "gl_host_circuit_verify": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz]),
+    "gl_common_data_to_bytes": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "gl_common_data_from_bytes": (c_int, [c_vp, c_sz, c_vp, c_vp]),
+    "gl_verifier_only_to_bytes": (c_int, [c_u32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "gl_verifier_only_from_bytes": (c_int, [c_vp, c_sz, c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "gl_verify_bytes": (c_int, [c_vp, c_sz, c_vp, c_sz]),
 }
 
 

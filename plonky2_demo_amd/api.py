@@ -617,6 +617,61 @@ class GenericCircuitData:
             pass
 
 
+# ------------------------------------------------------------------------------- circuit data as bytes (host code)
+def common_data_to_bytes(desc):
+    """CommonCircuitData::to_bytes of a gl_circuit_desc (util/serialization/mod.rs:1736-1790)."""
+    n = ctypes.c_size_t()
+    check(lib.gl_common_data_to_bytes(ctypes.byref(desc), None, 0, ctypes.byref(n)))
+    buf = np.empty(n.value, dtype=np.uint8)
+    check(lib.gl_common_data_to_bytes(ctypes.byref(desc), _p(buf), buf.size, ctypes.byref(n)))
+    return buf.tobytes()
+
+
+def common_data_from_bytes(data):
+    """-> (CircuitDesc, bytes consumed); GL_ERR_UNSUPPORTED for gates / features outside the demo's set."""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    d, used = _lib.CircuitDesc(), ctypes.c_size_t()
+    check(lib.gl_common_data_from_bytes(_p(buf), buf.size, ctypes.byref(d), ctypes.byref(used)))
+    return d, used.value
+
+
+def verifier_only_to_bytes(constants_sigmas_cap, circuit_digest):
+    cap, dig = _u64(constants_sigmas_cap).reshape(-1, 4), _u64(circuit_digest)
+    h = _log2_strict(cap.shape[0])
+    n = ctypes.c_size_t()
+    buf = np.empty(8 + 32 * cap.shape[0] + 32, dtype=np.uint8)
+    check(lib.gl_verifier_only_to_bytes(h, _p(cap), _p(dig), _p(buf), buf.size, ctypes.byref(n)))
+    return buf[: n.value].tobytes()
+
+
+def verifier_only_from_bytes(data):
+    """-> (cap[2^h][4], digest[4], bytes consumed)"""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    h, used = ctypes.c_uint32(), ctypes.c_size_t()
+    dig = np.empty(4, dtype=np.uint64)
+    check(lib.gl_verifier_only_from_bytes(_p(buf), buf.size, ctypes.byref(h), None, 0, _p(dig), ctypes.byref(used)))
+    cap = np.empty((1 << h.value, 4), dtype=np.uint64)
+    check(lib.gl_verifier_only_from_bytes(_p(buf), buf.size, ctypes.byref(h), _p(cap), cap.size, _p(dig), ctypes.byref(used)))
+    return cap, dig, used.value
+
+
+def verifier_data_to_bytes(desc, constants_sigmas_cap, circuit_digest):
+    """VerifierCircuitData::to_bytes = verifier_only || common (util/serialization/mod.rs:1908-1919)."""
+    return verifier_only_to_bytes(constants_sigmas_cap, circuit_digest) + common_data_to_bytes(desc)
+
+
+def verify_bytes(verifier_data, proof_bytes):
+    """VerifierCircuitData::from_bytes(verifier_data).verify(proof): (accepted, reason)."""
+    vd = np.frombuffer(bytes(verifier_data), dtype=np.uint8)
+    pb = np.frombuffer(bytes(proof_bytes), dtype=np.uint8)
+    st = lib.gl_verify_bytes(_p(vd), vd.size, _p(pb), pb.size)
+    if st == _lib.GL_OK:
+        return True, ""
+    if st == _lib.GL_ERR_VERIFY:
+        return False, (lib.gl_last_error() or b"").decode()
+    check(st)
+
+
 class ProverPool:
     """Many proofs in flight on one GPU from one call (gl_prover_pool_*): one circuit, `lanes` streams and host threads in C++."""
 

@@ -38,7 +38,7 @@ int gl_fail(int code, const char* what, const char* file, int line);
 // up RCCL blocks on an interrupt there: every one of the ~10 transcript round trips of a proof then pays a wake-up latency
 // (measured: 245 -> 210 proofs/s with a one-rank process group).  Polling is independent of what other libraries set.
 inline hipError_t gl_stream_wait(hipStream_t s) {
-    for (unsigned spins = 0;; spins++) {
+    for (;;) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
 #if defined(__x86_64__)

@@ -16,6 +16,13 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ gl_t glx_mk64(uint32_t lo, uint32_t hi) { return ((gl_t)hi << 32) | lo; }
+// z + bit * EPS (mod 2^64) for bit in {0, 1}: one multiply-add, no 64-bit pair to build for the addend
+__device__ __forceinline__ gl_t glx_add_eps_if(gl_t z, uint32_t bit) {
+    gl_t r;
+    asm("v_mad_u64_u32 %0, vcc, %1, -1, %2" : "=v"(r) : "v"(bit), "v"(z) : "vcc");
+    return r;
+}
+
 
 template <bool CANON>
 __device__ __forceinline__ void glx_mul3(gl_t aA, gl_t bA, gl_t aB, gl_t bB, gl_t aC, gl_t bC, gl_t& rA, gl_t& rB, gl_t& rC) {
@@ -213,8 +220,8 @@ __device__ __forceinline__ gl_t glx_mul(gl_t a, gl_t b) {
 __device__ __forceinline__ gl_t glx_reduce96(gl_t lo, uint32_t top) {
     gl_t z; uint64_t c; uint32_t e;
     asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"(top), "v"(lo));
-    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(e) : "s"(c));
-    return z + (gl_t)e;
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(e) : "s"(c));
+    return glx_add_eps_if(z, e);
 }
 // al + ah 2^32 (al, ah < 2^63) -> one word: the Poseidon MDS accumulators
 __device__ __forceinline__ gl_t glx_acc_reduce(gl_t al, gl_t ah) {
@@ -248,19 +255,19 @@ __device__ __forceinline__ void glx_acc_reduce3(gl_t alA, gl_t ahA, gl_t alB, gl
     asm("v_mad_u64_u32 %[zA], %[cA], %[tA], -1, %[loA]\n\t"
         "v_mad_u64_u32 %[zB], %[cB], %[tB], -1, %[loB]\n\t"
         "v_mad_u64_u32 %[zC], %[cC], %[tC], -1, %[loC]\n\t"
-        "v_cndmask_b32_e64 %[eA], 0, -1, %[cA]\n\t"
-        "v_cndmask_b32_e64 %[eB], 0, -1, %[cB]\n\t"
-        "v_cndmask_b32_e64 %[eC], 0, -1, %[cC]"
+        "v_cndmask_b32_e64 %[eA], 0, 1, %[cA]\n\t"
+        "v_cndmask_b32_e64 %[eB], 0, 1, %[cB]\n\t"
+        "v_cndmask_b32_e64 %[eC], 0, 1, %[cC]"
         : [zA] "=&v"(zA), [cA] "=&s"(cA), [zB] "=&v"(zB), [cB] "=&s"(cB), [zC] "=&v"(zC), [cC] "=&s"(cC), [eA] "=&v"(eA), [eB] "=&v"(eB), [eC] "=&v"(eC)
         : [tA] "v"(topA), [loA] "v"(loA), [tB] "v"(topB), [loB] "v"(loB), [tC] "v"(topC), [loC] "v"(loC));
-    rA = zA + (gl_t)eA; rB = zB + (gl_t)eB; rC = zC + (gl_t)eC;
+    rA = glx_add_eps_if(zA, eA); rB = glx_add_eps_if(zB, eB); rC = glx_add_eps_if(zC, eC);
 }
 
 // ---- canonical arithmetic for the NTT butterflies: operands < p in, results < p out (one fix-up each instead of two) ----------
-__device__ __forceinline__ gl_t glx_canon(gl_t x) { return x + ((x >= GL_P) ? GL_EPS : 0); }          // x - p mod 2^64
+__device__ __forceinline__ gl_t glx_canon(gl_t x) { return glx_add_eps_if(x, (x >= GL_P) ? 1u : 0u); }          // x - p mod 2^64
 __device__ __forceinline__ gl_t glx_add_cc(gl_t a, gl_t b) {                                             // 5 instructions
     const gl_t s = a + b;
-    return s + (((s < a) | (s >= GL_P)) ? GL_EPS : 0);
+    return glx_add_eps_if(s, ((s < a) | (s >= GL_P)) ? 1u : 0u);
 }
 __device__ __forceinline__ gl_t glx_sub_cc(gl_t a, gl_t b) {                                             // 5 instructions
 #ifdef GLX_C_BUTTERFLY
@@ -281,6 +288,39 @@ __device__ __forceinline__ gl_t glx_sub_cc(gl_t a, gl_t b) {                    
         : "vcc");
     return glx_mk64(r0, r1);
 }
+// four canonical differences at once: the borrow chains of four independent subtractions interleave, no wait states
+__device__ __forceinline__ void glx_sub_cc4(const gl_t (&a)[4], const gl_t (&b)[4], gl_t (&r)[4]) {
+    typedef uint32_t u32;
+    u32 r0A = (u32)a[0], r1A = (u32)(a[0] >> 32), r0B = (u32)a[1], r1B = (u32)(a[1] >> 32), r0C = (u32)a[2], r1C = (u32)(a[2] >> 32), r0D = (u32)a[3], r1D = (u32)(a[3] >> 32);
+    u32 eA, eB, eC, eD;
+    uint64_t sB, sC, sD;
+    asm("v_sub_co_u32 %[r0A], vcc, %[r0A], %[b0A]\n\t"
+        "v_sub_co_u32_e64 %[r0B], %[sB], %[r0B], %[b0B]\n\t"
+        "v_sub_co_u32_e64 %[r0C], %[sC], %[r0C], %[b0C]\n\t"
+        "v_sub_co_u32_e64 %[r0D], %[sD], %[r0D], %[b0D]\n\t"
+        "v_subb_co_u32 %[r1A], vcc, %[r1A], %[b1A], vcc\n\t"
+        "v_subb_co_u32_e64 %[r1B], %[sB], %[r1B], %[b1B], %[sB]\n\t"
+        "v_subb_co_u32_e64 %[r1C], %[sC], %[r1C], %[b1C], %[sC]\n\t"
+        "v_subb_co_u32_e64 %[r1D], %[sD], %[r1D], %[b1D], %[sD]\n\t"
+        "v_cndmask_b32_e64 %[eA], 0, -1, vcc\n\t"                       // borrow: + p = - EPS (mod 2^64)
+        "v_cndmask_b32_e64 %[eB], 0, -1, %[sB]\n\t"
+        "v_cndmask_b32_e64 %[eC], 0, -1, %[sC]\n\t"
+        "v_cndmask_b32_e64 %[eD], 0, -1, %[sD]\n\t"
+        "v_sub_co_u32 %[r0A], vcc, %[r0A], %[eA]\n\t"
+        "v_sub_co_u32_e64 %[r0B], %[sB], %[r0B], %[eB]\n\t"
+        "v_sub_co_u32_e64 %[r0C], %[sC], %[r0C], %[eC]\n\t"
+        "v_sub_co_u32_e64 %[r0D], %[sD], %[r0D], %[eD]\n\t"
+        "v_subbrev_co_u32 %[r1A], vcc, 0, %[r1A], vcc\n\t"
+        "v_subbrev_co_u32_e64 %[r1B], %[sB], 0, %[r1B], %[sB]\n\t"
+        "v_subbrev_co_u32_e64 %[r1C], %[sC], 0, %[r1C], %[sC]\n\t"
+        "v_subbrev_co_u32_e64 %[r1D], %[sD], 0, %[r1D], %[sD]"
+        : [r0A] "+v"(r0A), [r1A] "+v"(r1A), [r0B] "+v"(r0B), [r1B] "+v"(r1B), [r0C] "+v"(r0C), [r1C] "+v"(r1C), [r0D] "+v"(r0D), [r1D] "+v"(r1D),
+          [eA] "=&v"(eA), [eB] "=&v"(eB), [eC] "=&v"(eC), [eD] "=&v"(eD), [sB] "=&s"(sB), [sC] "=&s"(sC), [sD] "=&s"(sD)
+        : [b0A] "v"((u32)b[0]), [b1A] "v"((u32)(b[0] >> 32)), [b0B] "v"((u32)b[1]), [b1B] "v"((u32)(b[1] >> 32)),
+          [b0C] "v"((u32)b[2]), [b1C] "v"((u32)(b[2] >> 32)), [b0D] "v"((u32)b[3]), [b1D] "v"((u32)(b[3] >> 32))
+        : "vcc");
+    r[0] = glx_mk64(r0A, r1A); r[1] = glx_mk64(r0B, r1B); r[2] = glx_mk64(r0C, r1C); r[3] = glx_mk64(r0D, r1D);
+}
 // z (+ carry mask c) -> canonical: add EPS (= subtract p mod 2^64) when the carry is set or z >= p
 __device__ __forceinline__ gl_t glx_fix_canon(gl_t z, uint64_t c) {
     uint32_t e; uint64_t ge;
@@ -288,9 +328,9 @@ __device__ __forceinline__ gl_t glx_fix_canon(gl_t z, uint64_t c) {
         "v_cmp_gt_u64_e64 %[ge], %[z], %[pm1]\n\t"
         "s_nop 1\n\t"
         "s_or_b64 %[ge], %[ge], %[c]\n\t"
-        "v_cndmask_b32_e64 %[e], 0, -1, %[ge]"
+        "v_cndmask_b32_e64 %[e], 0, 1, %[ge]"
         : [e] "=v"(e), [ge] "=&s"(ge) : [z] "v"(z), [pm1] "s"(GL_P - 1), [c] "s"(c) : "scc");
-    return z + (gl_t)e;
+    return glx_add_eps_if(z, e);
 }
 // canonical x times 2^E (0 < E < 96), canonical result: the butterfly twiddles (the reference's w_64 = 2^39, 2^96 = -1)
 template <int E>
@@ -361,8 +401,10 @@ template <bool CANON>
 __device__ gl_t glx_mul(gl_t a, gl_t b);
 __device__ gl_t glx_reduce96(gl_t lo, uint32_t top);
 __device__ gl_t glx_canon(gl_t x);
+__device__ gl_t glx_add_eps_if(gl_t z, uint32_t bit);
 __device__ gl_t glx_add_cc(gl_t a, gl_t b);
 __device__ gl_t glx_sub_cc(gl_t a, gl_t b);
+__device__ void glx_sub_cc4(const gl_t (&a)[4], const gl_t (&b)[4], gl_t (&r)[4]);
 template <int E>
 __device__ gl_t glx_shl_c(gl_t x);
 __device__ gl_t glx_acc_reduce(gl_t al, gl_t ah);

@@ -67,30 +67,58 @@ __device__ __forceinline__ gl_t ntt_shift_twiddle(gl_t x) {
     if constexpr (E == 0) return x;
     else return glx_shl_c<(int)E>(x);
 }
-template <int LOGR, bool INV, int LG, int B, int I>
-__device__ __forceinline__ void ntt_small_dft_bfly(gl_t* u) {
-    constexpr int s = 1 << (LG - 1);
-    // w_{2s}^i = 2^(39 * (32/s) * i); 2^96 = -1, so a twiddle -2^k is applied as (c - a) * 2^k: no negation
-    constexpr unsigned e0 = (39u * (32u / (unsigned)s) * (unsigned)I) % 192u;
-    constexpr unsigned e = INV ? (192u - e0) % 192u : e0;
-    const gl_t a = u[B + I], c = u[B + I + s];
-    u[B + I] = glx_add_cc(a, c);
-    const gl_t d = (e >= 96u) ? glx_sub_cc(c, a) : glx_sub_cc(a, c);
-    u[B + I + s] = ntt_shift_twiddle<e % 96u>(d);
+// exponent of the twiddle of butterfly K (0 <= K < R/2) of the layer with half-size s = 2^(LG-1): butterfly K pairs u[b + i] with
+// u[b + i + s], b = (K / s) * 2s, i = K % s, twiddle w_{2s}^i = 2^(39 * (32/s) * i) (the reference's w_64 = 2^39)
+template <int LOGR, bool INV, int LG, int K>
+struct NttBfly {
+    static constexpr int s = 1 << (LG - 1), i = K % s, lo = (K / s) * 2 * s + i, hi = lo + s;
+    static constexpr unsigned e0 = (39u * (32u / (unsigned)s) * (unsigned)i) % 192u;
+    static constexpr unsigned e = INV ? (192u - e0) % 192u : e0;
+};
+// differences of the butterflies K0 .. K0+3 of a layer, four at a time (2^96 = -1: a twiddle -2^k is applied as (c - a) * 2^k)
+template <int LOGR, bool INV, int LG, int K0>
+__device__ __forceinline__ void ntt_layer_diffs4(const gl_t* u, gl_t* d) {
+    gl_t a[4], b[4], r[4];
+#define NTT_PICK(k)                                                                                   \
+    { using Bf = NttBfly<LOGR, INV, LG, K0 + k>;                                                      \
+      if constexpr (Bf::e >= 96u) { a[k] = u[Bf::hi]; b[k] = u[Bf::lo]; } else { a[k] = u[Bf::lo]; b[k] = u[Bf::hi]; } }
+    NTT_PICK(0) NTT_PICK(1) NTT_PICK(2) NTT_PICK(3)
+#undef NTT_PICK
+    glx_sub_cc4(a, b, r);
+    d[K0] = r[0]; d[K0 + 1] = r[1]; d[K0 + 2] = r[2]; d[K0 + 3] = r[3];
 }
-template <int LOGR, bool INV, int LG, int B, int I>
-__device__ __forceinline__ void ntt_small_dft_i(gl_t* u) {
-    constexpr int s = 1 << (LG - 1);
-    if constexpr (I < s) { ntt_small_dft_bfly<LOGR, INV, LG, B, I>(u); ntt_small_dft_i<LOGR, INV, LG, B, I + 1>(u); }
-}
-template <int LOGR, bool INV, int LG, int B>
-__device__ __forceinline__ void ntt_small_dft_b(gl_t* u) {
-    constexpr int R = 1 << LOGR, s = 1 << (LG - 1);
-    if constexpr (B < R) { ntt_small_dft_i<LOGR, INV, LG, B, 0>(u); ntt_small_dft_b<LOGR, INV, LG, B + 2 * s>(u); }
+template <int LOGR, bool INV, int LG, int K>
+__device__ __forceinline__ void ntt_layer_finish(gl_t* u, const gl_t* d) {
+    constexpr int H = 1 << (LOGR - 1);
+    if constexpr (K < H) {
+        using Bf = NttBfly<LOGR, INV, LG, K>;
+        u[Bf::lo] = glx_add_cc(u[Bf::lo], u[Bf::hi]);
+        u[Bf::hi] = ntt_shift_twiddle<Bf::e % 96u>(d[K]);
+        ntt_layer_finish<LOGR, INV, LG, K + 1>(u, d);
+    }
 }
 template <int LOGR, bool INV, int LG>
 __device__ __forceinline__ void ntt_small_dft_l(gl_t* u) {
-    if constexpr (LG >= 1) { ntt_small_dft_b<LOGR, INV, LG, 0>(u); ntt_small_dft_l<LOGR, INV, LG - 1>(u); }
+    if constexpr (LG >= 1) {
+        constexpr int H = 1 << (LOGR - 1);              // butterflies per layer
+        gl_t d[H];
+        if constexpr (H >= 4) {
+            ntt_layer_diffs4<LOGR, INV, LG, 0>(u, d);
+            if constexpr (H >= 8) ntt_layer_diffs4<LOGR, INV, LG, 4>(u, d);
+            static_assert(H <= 8, "radix at most 16");
+        } else {
+#pragma unroll
+            for (int k = 0; k < H; k++) {
+                // H is 1 or 2: single subtractions
+                const int s = 1 << (LG - 1), i = k % s, lo = (k / s) * 2 * s + i, hi = lo + s;
+                unsigned e = (39u * (32u / (unsigned)s) * (unsigned)i) % 192u;
+                if (INV) e = (192u - e) % 192u;
+                d[k] = (e >= 96u) ? glx_sub_cc(u[hi], u[lo]) : glx_sub_cc(u[lo], u[hi]);
+            }
+        }
+        ntt_layer_finish<LOGR, INV, LG, 0>(u, d);
+        ntt_small_dft_l<LOGR, INV, LG - 1>(u);
+    }
 }
 // In-register DFT of R = 2^LOGR points (decimation in frequency) on canonical values; X[q] is left in u[bitrev(q)].
 template <int LOGR, bool INV>
@@ -220,9 +248,14 @@ __device__ __forceinline__ void ntt_lds_stages(gl_t* lds, const gl_t* __restrict
     }
 }
 
+// Element `i` of a polynomial through a 32-bit BYTE offset from the (uniform) base: the access becomes "scalar base + one 32-bit
+// vector offset" instead of four 64-bit address instructions per element.  Valid for i < 2^29 (transforms are at most 2^24).
+__device__ __forceinline__ gl_t ntt_ld(const gl_t* base, uint32_t i) { return *(const gl_t*)((const char*)base + (i << 3)); }
+__device__ __forceinline__ void ntt_st(gl_t* base, uint32_t i, gl_t x) { *(gl_t*)((char*)base + (i << 3)) = x; }
+
 // COLUMN pass (pass A).  grid = (N2 / T, batch).
 template <int LOGL, bool INV, bool ZP = false>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_col_pass(NttPassParams p) {
+__global__ __launch_bounds__(NTT_THREADS, 4) void ntt_col_pass(NttPassParams p) {
     using G = NttGeom<LOGL>;
     constexpr int LOGT = G::LOGT, T = G::T;
     extern __shared__ __align__(16) gl_t lds[];
@@ -244,7 +277,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_col_pass(NttPassParams p) {
         const int e = tid + NTT_THREADS * q;
         const uint32_t t = e & (T - 1), i1 = e >> LOGT;
         const uint32_t i = (i1 << lgN2) + c0 + t;
-        v[q] = NTT_DBG(p, 2) ? (gl_t)e : ((i < p.n_in) ? src[i] : (gl_t)0);
+        v[q] = NTT_DBG(p, 2) ? (gl_t)e : ((i < p.n_in) ? ntt_ld(src, i) : (gl_t)0);
     }
 #pragma unroll
     for (int q = 0; q < QLOAD; q++) {
@@ -260,43 +293,44 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_col_pass(NttPassParams p) {
     if (!NTT_DBG(p, 1)) ntt_lds_stages<LOGL, 0, INV, ZP>(lds, p.tw_local, tid);
     if constexpr (G::WAVE_OWNED) __syncthreads();
     // store with the inter-pass twiddle w_N^(i2*k1); the products go three at a time
-    auto elem = [&](int q, gl_t& x, gl_t& tw, uint64_t& o) {
+    const gl_t* tw_pass = p.tw_pass;
+    auto elem = [&](int q, gl_t& x, gl_t& tw, uint32_t& o) {
         const int e = tid + NTT_THREADS * q;
         const uint32_t t = e & (T - 1), k1 = e >> LOGT;
         const uint32_t i2 = c0 + t;
         x = lds[G::at(t, k1)];
-        o = ((uint64_t)k1 << lgN2) + i2;
-        tw = p.tw_pass ? p.tw_pass[o] : ntt_pow2level(p.tw_lo, p.tw_hi, i2 * k1);
+        o = (k1 << lgN2) + i2;
+        tw = tw_pass ? ntt_ld(tw_pass, o) : ntt_pow2level(p.tw_lo, p.tw_hi, i2 * k1);
     };
     constexpr int QG = NTT_EPT / 3 * 3;
-#pragma unroll 2
+#pragma unroll 1
     for (int q = 0; q < QG; q += 3) {
-        gl_t x[3], tw[3]; uint64_t o[3];
+        gl_t x[3], tw[3]; uint32_t o[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) elem(q + k, x[k], tw[k], o[k]);
         glx_mul3<true>(x[0], tw[0], x[1], tw[1], x[2], tw[2], x[0], x[1], x[2]);
 #pragma unroll
-        for (int k = 0; k < 3; k++) if (!NTT_DBG(p, 4) || x[k] == 12345) dst[o[k]] = x[k];
+        for (int k = 0; k < 3; k++) if (!NTT_DBG(p, 4) || x[k] == 12345) ntt_st(dst, o[k], x[k]);
     }
 #pragma unroll
     for (int q = QG; q < NTT_EPT; q++) {
-        gl_t x, tw; uint64_t o;
+        gl_t x, tw; uint32_t o;
         elem(q, x, tw, o);
         x = glx_mul<true>(x, tw);
-        if (!NTT_DBG(p, 4) || x == 12345) dst[o] = x;
+        if (!NTT_DBG(p, 4) || x == 12345) ntt_st(dst, o, x);
     }
 }
 
 // ROW pass (pass B, or the only pass when lgN1 == 0).
 //   two-pass:   grid = (N1 / T, batch): rows k1 of one polynomial
 //   single:     grid = (ceil(batch / T), 1): T polynomials
-template <int LOGL, bool INV>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_row_pass(NttPassParams p) {
+template <int LOGL, bool INV, bool SINGLE>
+__global__ __launch_bounds__(NTT_THREADS, 4) void ntt_row_pass(NttPassParams p) {
     using G = NttGeom<LOGL>;
     constexpr int LOGT = G::LOGT, T = G::T, L = G::L;
     extern __shared__ __align__(16) gl_t lds[];
     const int tid = threadIdx.x;
-    const bool single = (p.lgN1 == 0);
+    constexpr bool single = SINGLE;                         // == (p.lgN1 == 0)
     uint32_t tile = blockIdx.x;
     if (!single && (gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const uint32_t r0 = tile << LOGT;                       // first row (k1) or first polynomial
@@ -313,7 +347,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_row_pass(NttPassParams p) {
             const uint32_t poly = r0 + r;
             v[q] = (poly < p.batch && i2 < p.n_in) ? p.src[(uint64_t)poly * p.src_stride + i2] : 0;
         } else {
-            v[q] = NTT_DBG(p, 2) ? (gl_t)e : src[((uint64_t)(r0 + r) << LOGL) + i2];
+            v[q] = NTT_DBG(p, 2) ? (gl_t)e : ntt_ld(src, ((r0 + r) << LOGL) + i2);
         }
     }
 #pragma unroll
@@ -355,7 +389,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_row_pass(NttPassParams p) {
             gl_t x = lds[G::at(r, k2)];
             if (p.post_lo) x = glx_mul<true>(x, ntt_pow2level(p.post_lo, p.post_hi, k));
             else if (p.post_const != 1) x = glx_mul<true>(x, p.post_const);
-            if (!NTT_DBG(p, 4) || x == 12345) dst[k] = x;
+            if (!NTT_DBG(p, 4) || x == 12345) ntt_st(dst, k, x);
         }
     }
 }

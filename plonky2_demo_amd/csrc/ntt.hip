@@ -309,19 +309,23 @@ static int launch_col(gl_ctx* c, const NttPassParams& p, dim3 grid) {
     }
     return launch_col_impl<LOGL, INV, false>(c, p, grid);
 }
-template <int LOGL, bool INV>
-static int launch_row(gl_ctx* c, const NttPassParams& p, dim3 grid) {
+template <int LOGL, bool INV, bool SINGLE>
+static int launch_row_impl(gl_ctx* c, const NttPassParams& p, dim3 grid) {
     constexpr size_t lds = NttGeom<LOGL>::LDS_BYTES;
     static std::atomic<uint64_t> done{0};
     const uint64_t bit = uint64_t(1) << (c->device & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        GL_CHECK_HIP(hipFuncSetAttribute((const void*)ntt_row_pass<LOGL, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GL_CHECK_HIP(hipFuncSetAttribute((const void*)ntt_row_pass<LOGL, INV, SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         done.fetch_or(bit, std::memory_order_release);
     }
     GlTimed timed(c, INV ? "ntt_row_pass(inverse)" : "ntt_row_pass(forward)");
-    hipLaunchKernelGGL((ntt_row_pass<LOGL, INV>), grid, dim3(NTT_THREADS), lds, c->stream, p);
+    hipLaunchKernelGGL((ntt_row_pass<LOGL, INV, SINGLE>), grid, dim3(NTT_THREADS), lds, c->stream, p);
     GL_CHECK_HIP(hipGetLastError());
     return GL_OK;
+}
+template <int LOGL, bool INV>
+static int launch_row(gl_ctx* c, const NttPassParams& p, dim3 grid) {
+    return p.lgN1 == 0 ? launch_row_impl<LOGL, INV, true>(c, p, grid) : launch_row_impl<LOGL, INV, false>(c, p, grid);
 }
 
 #define NTT_DISPATCH(fn, logl, inv, ...)                                             \

@@ -244,6 +244,15 @@ class OracleCircuit:
         self.n = 1 << self.info["degree_bits"]
         return self
 
+    def data_bytes(self, kind):
+        """kind 0: CommonCircuitData::to_bytes, 1: VerifierCircuitData::to_bytes, by the oracle's own writer."""
+        lib = self.o.lib
+        lib.orc_circuit_data_bytes.restype = _sz
+        n = lib.orc_circuit_data_bytes(self.h, ctypes.c_int(kind), None, _sz(0))
+        buf = np.empty(n, dtype=np.uint8)
+        lib.orc_circuit_data_bytes(self.h, ctypes.c_int(kind), _p(buf), _sz(n))
+        return buf.tobytes()
+
     def product_desc(self):
         """The gl_circuit_desc (plonky2_demo_amd._lib.CircuitDesc) of this circuit, for gl_circuit_create / gl_verify."""
         from plonky2_demo_amd._lib import CircuitDesc

@@ -120,3 +120,65 @@ def test_other_circuit_shapes_over_the_same_gate_set(orc, kind, param):
     bad[len(by) // 3] ^= 2
     assert lib.gl_verify(ctypes.byref(desc), vp(cap), vp(dig), vp(bad), bad.size) == GL_ERR_VERIFY
     assert (kind == 2) == (len(w.public_inputs()) == 0)
+
+
+# ------------------------------------------------------------------------------------------ circuit data as bytes
+# PARITY UNPINNED against the Rust writer: the reference ships no serialised circuit.  What pins these bytes here: the
+# product's writer and the oracle's own writer (two restatements of util/serialization/mod.rs:1596-1790,1889-1919) agree byte for
+# byte, the reader inverts the writer, and verification through the byte form gives the same verdicts.
+@pytest.mark.parametrize("m", [1, 2, 3, 8, 20])
+def test_common_and_verifier_data_bytes_match_the_oracle_writer_and_round_trip(orc, m):
+    import ctypes
+    import plonky2_demo_amd as p
+    from plonky2_demo_amd import api
+    hc = p.MatmulCircuit(m)
+    oc = orc.circuit(m, threads=4)
+    common = api.common_data_to_bytes(hc.desc)
+    assert common == oc.data_bytes(0)
+    d2, used = api.common_data_from_bytes(common)
+    assert used == len(common)
+    assert bytes(d2) == bytes(hc.desc)                       # every field of the gl_circuit_desc survives the round trip
+    assert api.common_data_to_bytes(d2) == common
+    cap, dig = oc.constants_sigmas_cap, oc.digest
+    vd = api.verifier_data_to_bytes(hc.desc, cap, dig)
+    assert vd == oc.data_bytes(1)
+    cap2, dig2, used2 = api.verifier_only_from_bytes(vd)
+    assert (cap2 == cap).all() and (dig2 == dig).all() and used2 == 8 + 32 * 16 + 32
+    # layout facts of the reference's writer: usize = u64 LE (mod.rs:1220-1222), the cap height first (mod.rs:1901)
+    assert vd[:8] == (4).to_bytes(8, "little") and common[:8] == (135).to_bytes(8, "little")
+    # verification through the byte form: same verdicts as the structured form
+    a, b = rand_field(m, m * m) % (2**32 - 1), rand_field(m + 7, m * m) % (2**32 - 1)
+    proof = oc.witness(a, b, filler_seed=3).prove(threads=4).to_bytes()
+    assert api.verify_bytes(vd, proof) == (True, "")
+    bad = bytearray(proof); bad[40] ^= 1
+    ok, why = api.verify_bytes(vd, bytes(bad))
+    assert not ok and why
+    with pytest.raises(p.Plonky2Mi355xError):
+        api.verify_bytes(vd[:-1], proof)                     # truncated verifier data
+    with pytest.raises(p.Plonky2Mi355xError):
+        api.verify_bytes(vd + b"\0", proof)                  # trailing bytes
+
+
+def test_common_data_reader_rejects_what_the_library_cannot_prove(orc):
+    import plonky2_demo_amd as p
+    from plonky2_demo_amd import api
+    hc = p.MatmulCircuit(2)
+    good = bytearray(api.common_data_to_bytes(hc.desc))
+    # the first gate tag sits after config (6 usize + 2 bool + fri config 3 usize + u32 + 1 + 2 usize), fri params (the same fri
+    # config + arity vector + degree + bool) and the gate count
+    fri = 3 * 8 + 4 + 1 + 16
+    off = 6 * 8 + 2 + fri + fri + 8 + 8 * hc.desc.num_fri_rounds + 8 + 1 + 8
+    assert int.from_bytes(good[off:off + 4], "little") in (0, 3, 9, 11, 12)
+    bad = bytearray(good); bad[off:off + 4] = (13).to_bytes(4, "little")         # RandomAccessGate
+    with pytest.raises(p.Plonky2Mi355xError) as e:
+        api.common_data_from_bytes(bytes(bad))
+    assert e.value.code == 3                                                       # GL_ERR_UNSUPPORTED
+    bad = bytearray(good); bad[6 * 8 + 1] = 1                                      # zero_knowledge = true
+    with pytest.raises(p.Plonky2Mi355xError):
+        api.common_data_from_bytes(bytes(bad))
+    bad = bytearray(good); bad[-8:] = (1).to_bytes(8, "little")                    # one lookup table
+    with pytest.raises(p.Plonky2Mi355xError):
+        api.common_data_from_bytes(bytes(bad))
+    for cut in (0, 7, 60, len(good) - 1):
+        with pytest.raises(p.Plonky2Mi355xError):
+            api.common_data_from_bytes(bytes(good[:cut]))

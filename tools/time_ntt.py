@@ -10,6 +10,8 @@ lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 ctx = p.default_context()
+if len(sys.argv) > 4:
+    ctx.set_scratch_elems(1 << int(sys.argv[4]))      # inter-pass scratch (elements): chunk = scratch / 2^lg polynomials
 rng = np.random.default_rng(1)
 x = rng.integers(0, 2**63, (batch, 1 << lg), dtype=np.uint64)
 d = ctx.alloc(x.nbytes).upload(x)
