@@ -202,7 +202,16 @@ void gl_matmul_witgen_free(gl_matmul_witgen* g);
 /* The device half of build(): PolynomialBatch::from_values(constants || sigmas) (circuit_builder.rs:1020-1028),
  * circuit_digest (:1089-1100), sigma / subgroup tables.  h_constants_sigmas[(num_constants + 80)][n]. */
 int gl_circuit_create(gl_ctx* ctx, const gl_circuit_desc* desc, const uint64_t* h_constants_sigmas, gl_circuit** out);
+/* The same with the sigma polynomials computed ON THE DEVICE (circuit_builder.rs:1007-1014 sigma_vecs; plonk/permutation_argument.rs:
+ * 85-170): h_wire_classes[80][n] holds, for every routed wire (wire (row, col) at col * n + row), the id of its copy-constraint
+ * class -- the representative the reference's union-find Forest assigns; any u64, equal ids = wires constrained equal.
+ * h_constants[num_constants][n] are the selector and gate-constant VALUE columns. */
+int gl_circuit_create_from_classes(gl_ctx* ctx, const gl_circuit_desc* desc, const uint64_t* h_constants, const uint64_t* h_wire_classes,
+                                   gl_circuit** out);
+/* build() of the demo circuit: constants from the host description, sigma polynomials on the device */
 int gl_circuit_from_host(gl_ctx* ctx, const gl_host_circuit* hc, gl_circuit** out);
+/* the wire classes of the host description, h_out[80][n] (gl_circuit_create_from_classes takes them) */
+int gl_host_circuit_wire_classes(const gl_host_circuit* hc, uint64_t* h_out);
 int gl_circuit_digest(const gl_circuit* c, uint64_t h_out[4]);                 /* verifier_only.circuit_digest */
 int gl_circuit_constants_sigmas_cap(const gl_circuit* c, uint64_t* h_out);     /* [2^cap_height][4]            */
 const gl_batch* gl_circuit_constants_sigmas_batch(const gl_circuit* c);

@@ -131,6 +131,8 @@ SIGNATURES = {
     "gl_proof_free": (None, [c_vp]),
     "gl_verify": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz]),
     "gl_host_circuit_verify": (c_int, [c_vp, c_vp, c_vp, c_vp, c_sz]),
+    "gl_circuit_create_from_classes": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "gl_host_circuit_wire_classes": (c_int, [c_vp, c_vp]),
     "gl_common_data_to_bytes": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "gl_common_data_from_bytes": (c_int, [c_vp, c_sz, c_vp, c_vp]),
     "gl_verifier_only_to_bytes": (c_int, [c_u32, c_vp, c_vp, c_vp, c_sz, c_vp]),

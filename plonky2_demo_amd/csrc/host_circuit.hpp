@@ -9,6 +9,7 @@
 // and the copy-constraint classes are enumerated directly instead of through a union-find forest.
 #pragma once
 #include <stdint.h>
+#include <mutex>
 #include <string.h>
 #include <algorithm>
 #include <array>
@@ -45,7 +46,10 @@ struct HostCircuit {
     gl_circuit_desc desc;
     size_t m = 0, n = 0;
     std::vector<uint8_t> row_gate;                     // gate type per row
-    std::vector<gl_t> constants_sigmas;                // column-major [num_constants + 80][n] VALUES
+    std::vector<gl_t> constants_sigmas;                // column-major [num_constants + 80][n] VALUES; the sigma part is filled on demand
+    std::vector<uint64_t> wire_class;                  // [80][n]: copy-constraint class of every routed wire (equal id = constrained equal)
+    mutable std::once_flag sigmas_once;                // host sigma values are only needed by callers that ask for the columns
+    void ensure_host_sigmas() const;
     // witness recipe
     size_t first_poseidon_row = 0, num_poseidon_rows = 0, pi_row = 0, constant_row = 0;
     std::vector<uint32_t> mul_row, add_row;            // row of the t-th mul / add row-block (20 ops each)
@@ -143,7 +147,8 @@ inline int build_matmul(size_t m, HostCircuit* hc) {
     // Every routed wire gets a class key; wires with equal keys are one partition subset.  Keys:
     enum : uint64_t { K_A = 1ull << 60, K_B = 2ull << 60, K_PROD = 3ull << 60, K_SUM = 4ull << 60, K_ZERO = 5ull << 60,
                       K_ONE = 6ull << 60, K_HOUT = 7ull << 60, K_SELF = 8ull << 60 };
-    std::vector<uint64_t> key(80 * n);
+    std::vector<uint64_t>& key = hc->wire_class;
+    key.assign(80 * n, 0);
     for (size_t r = 0; r < n; r++) for (size_t c = 0; c < 80; c++) key[c * n + r] = K_SELF | (c * n + r);
     auto setk = [&](size_t row, size_t col, uint64_t k) { if (col < 80) key[col * n + row] = k; };
     // public-input target t (order a_ij, b_ij, c_ij per (i,j)): key of the value it carries
@@ -180,23 +185,6 @@ inline int build_matmul(size_t m, HostCircuit* hc) {
         for (int t = 0; t < 4; t++) setk(hc->pi_row, t, state[t]);
     }
     setk(hc->constant_row, 0, K_ZERO); setk(hc->constant_row, 1, K_ONE);
-    // sort wire positions by (key, row, col); the reference orders a subset by (row, column)
-    std::vector<uint32_t> order(80 * n);
-    for (size_t p = 0; p < order.size(); p++) order[p] = (uint32_t)p;
-    auto rowcol = [&](uint32_t p) { return (uint64_t)(p % n) * 80 + p / n; };
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key[x] != key[y] ? key[x] < key[y] : rowcol(x) < rowcol(y); });
-    std::vector<gl_t> subgroup(n);
-    { gl_t g = root_of_unity(lg), x = 1; for (size_t i = 0; i < n; i++) { subgroup[i] = x; x = gl_canon(gl_mul(x, g)); } }
-    gl_t* sig = cs + (size_t)d.num_constants * n;
-    for (size_t s = 0; s < order.size();) {
-        size_t e = s;
-        while (e < order.size() && key[order[e]] == key[order[s]]) e++;
-        for (size_t q = s; q < e; q++) {
-            uint32_t me = order[q], nb = order[q + 1 < e ? q + 1 : s];
-            sig[me] = gl_canon(gl_mul(d.k_is[nb / n], subgroup[nb % n]));      // sigma(me) = k_col(nb) * w^row(nb)
-        }
-        s = e;
-    }
     return GL_OK;
 }
 
@@ -286,6 +274,37 @@ inline int matmul_witness(const HostCircuit& hc, const gl_t* a, const gl_t* b, u
     return GL_OK;
 }
 
+
+// sigma VALUES on the host from the wire classes (permutation_argument.rs:85-170, circuit_builder.rs:1007-1014): every class is a
+// cycle through its wires in (row, column) order; sigma(wire) = k_col(next) * w^row(next).  The device does the same in
+// sigma.hip; this host form serves gl_host_circuit_constants_sigmas and the tests.
+inline void HostCircuit::ensure_host_sigmas() const {
+    std::call_once(sigmas_once, [this] {
+        HostCircuit* hc = const_cast<HostCircuit*>(this);
+        const gl_circuit_desc& d = hc->desc;
+        const size_t n = hc->n;
+        const unsigned lg = d.degree_bits;
+        const std::vector<uint64_t>& key = hc->wire_class;
+        gl_t* cs = hc->constants_sigmas.data();
+        // sort wire positions by (key, row, col); the reference orders a subset by (row, column)
+        std::vector<uint32_t> order(80 * n);
+        for (size_t p = 0; p < order.size(); p++) order[p] = (uint32_t)p;
+        auto rowcol = [&](uint32_t p) { return (uint64_t)(p % n) * 80 + p / n; };
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key[x] != key[y] ? key[x] < key[y] : rowcol(x) < rowcol(y); });
+        std::vector<gl_t> subgroup(n);
+        { gl_t g = root_of_unity(lg), x = 1; for (size_t i = 0; i < n; i++) { subgroup[i] = x; x = gl_canon(gl_mul(x, g)); } }
+        gl_t* sig = cs + (size_t)d.num_constants * n;
+        for (size_t s = 0; s < order.size();) {
+            size_t e = s;
+            while (e < order.size() && key[order[e]] == key[order[s]]) e++;
+            for (size_t q = s; q < e; q++) {
+                uint32_t me = order[q], nb = order[q + 1 < e ? q + 1 : s];
+                sig[me] = gl_canon(gl_mul(d.k_is[nb / n], subgroup[nb % n]));      // sigma(me) = k_col(nb) * w^row(nb)
+            }
+            s = e;
+        }
+    });
+}
 }  // namespace glhost
 
 struct gl_host_circuit { glhost::HostCircuit hc; };     // the opaque handle of include/plonky2_mi355x.h

@@ -29,6 +29,15 @@ struct gl_proof {
     std::vector<uint64_t> query_indices;
 };
 
+struct DevBuf {                     // RAII block from the context's stream-ordered pool
+    gl_ctx* c; void* p = nullptr;
+    explicit DevBuf(gl_ctx* ctx) : c(ctx) {}
+    int alloc(size_t bytes) { return c->pool_alloc(bytes, &p); }
+    void release() { if (p) { c->pool_release(p); p = nullptr; } }
+    ~DevBuf() { release(); }
+    template <class T> T* as() const { return (T*)p; }
+};
+
 // ---- host Challenger (iop/challenger.rs:30-153) -----------------------------------------------------------------
 struct HostChallenger {
     gl_t state[12]; gl_t in[8]; int nin = 0; gl_t out[8]; int nout = 0;
@@ -89,6 +98,7 @@ extern "C" int gl_host_circuit_row_gates(const gl_host_circuit* hc, uint8_t* h_o
 }
 extern "C" int gl_host_circuit_constants_sigmas(const gl_host_circuit* hc, uint64_t* h_out) {
     GL_REQUIRE(hc && h_out, GL_ERR_ARG, "null argument");
+    hc->hc.ensure_host_sigmas();
     memcpy(h_out, hc->hc.constants_sigmas.data(), hc->hc.constants_sigmas.size() * sizeof(gl_t));
     return GL_OK;
 }
@@ -125,18 +135,16 @@ extern "C" void gl_circuit_free(gl_circuit* c) {
     delete c;
 }
 
-extern "C" int gl_circuit_create(gl_ctx* ctx, const gl_circuit_desc* desc, const uint64_t* h_cs, gl_circuit** out) {
-    GL_REQUIRE(ctx && desc && h_cs && out, GL_ERR_ARG, "null argument");
-    GL_TRY(validate_desc(*desc));
-    GL_TRY(ctx->activate());
+int gl_sigmas_from_classes(gl_ctx* c, const uint64_t* d_classes, uint32_t lgn, uint32_t ncols, const uint64_t* h_k_is, gl_t* d_sigma);      // sigma.hip
+
+// the rest of the device half of build() once the constants || sigmas VALUE columns are in HBM (d_cs[num_constants + 80][n])
+static int circuit_finish(gl_ctx* ctx, const gl_circuit_desc* desc, const gl_t* d_cs, gl_circuit** out) {
     std::unique_ptr<gl_circuit, void (*)(gl_circuit*)> c(new gl_circuit(), gl_circuit_free);
     c->ctx = ctx; ctx->retain(); c->desc = *desc; c->n = size_t(1) << desc->degree_bits;
     const size_t n = c->n, ncs = desc->num_constants + 80;
-    std::vector<const uint64_t*> cols(ncs);
-    for (size_t k = 0; k < ncs; k++) cols[k] = h_cs + k * n;
-    GL_TRY(gl_batch_from_values(ctx, cols.data(), ncs, n, desc->rate_bits, 0, desc->cap_height, &c->cs_batch));   // circuit_builder.rs:1020-1028
+    GL_TRY(gl_batch_from_device(ctx, d_cs, ncs, n, desc->rate_bits, desc->cap_height, 1, &c->cs_batch));      // circuit_builder.rs:1020-1028
     GL_TRY(ctx->pool_alloc(80 * n * sizeof(gl_t), (void**)&c->d_sigmas));
-    GL_TRY(gl_copy_h2d(ctx, c->d_sigmas, h_cs + (size_t)desc->num_constants * n, 80 * n * sizeof(gl_t)));
+    GL_CHECK_HIP(hipMemcpyAsync(c->d_sigmas, d_cs + (size_t)desc->num_constants * n, 80 * n * sizeof(gl_t), hipMemcpyDeviceToDevice, ctx->stream));
     {   // L_0 on the coset 7 H_N, N = n << rate_bits
         const uint32_t lgN = desc->degree_bits + desc->rate_bits;
         const size_t N = size_t(1) << lgN;
@@ -164,9 +172,41 @@ extern "C" int gl_circuit_create(gl_ctx* ctx, const gl_circuit_desc* desc, const
     *out = c.release();
     return GL_OK;
 }
+extern "C" int gl_circuit_create(gl_ctx* ctx, const gl_circuit_desc* desc, const uint64_t* h_cs, gl_circuit** out) {
+    GL_REQUIRE(ctx && desc && h_cs && out, GL_ERR_ARG, "null argument");
+    GL_TRY(validate_desc(*desc));
+    GL_TRY(ctx->activate());
+    const size_t n = size_t(1) << desc->degree_bits, ncs = desc->num_constants + 80;
+    DevBuf d_cs(ctx); GL_TRY(d_cs.alloc(ncs * n * sizeof(gl_t)));
+    GL_TRY(gl_copy_h2d(ctx, d_cs.p, h_cs, ncs * n * sizeof(gl_t)));
+    return circuit_finish(ctx, desc, d_cs.as<gl_t>(), out);
+}
+// build() with the sigma polynomials computed on the device from the copy-constraint classes (sigma.hip)
+extern "C" int gl_circuit_create_from_classes(gl_ctx* ctx, const gl_circuit_desc* desc, const uint64_t* h_constants, const uint64_t* h_wire_classes, gl_circuit** out) {
+    GL_REQUIRE(ctx && desc && h_constants && h_wire_classes && out, GL_ERR_ARG, "null argument");
+    GL_TRY(validate_desc(*desc));
+    GL_TRY(ctx->activate());
+    const size_t n = size_t(1) << desc->degree_bits, nc = desc->num_constants;
+    DevBuf d_cs(ctx), d_cls(ctx);
+    GL_TRY(d_cs.alloc((nc + 80) * n * sizeof(gl_t)));
+    GL_TRY(d_cls.alloc(80 * n * sizeof(uint64_t)));
+    GL_TRY(gl_copy_h2d(ctx, d_cs.p, h_constants, nc * n * sizeof(gl_t)));
+    GL_TRY(gl_copy_h2d(ctx, d_cls.p, h_wire_classes, 80 * n * sizeof(uint64_t)));
+    ctx->timing_begin("sigma polynomials");
+    int st = gl_sigmas_from_classes(ctx, d_cls.as<uint64_t>(), desc->degree_bits, 80, desc->k_is, d_cs.as<gl_t>() + nc * n);
+    ctx->timing_end();
+    GL_TRY(st);
+    return circuit_finish(ctx, desc, d_cs.as<gl_t>(), out);
+}
 extern "C" int gl_circuit_from_host(gl_ctx* ctx, const gl_host_circuit* hc, gl_circuit** out) {
     GL_REQUIRE(hc, GL_ERR_ARG, "null host circuit");
-    return gl_circuit_create(ctx, &hc->hc.desc, hc->hc.constants_sigmas.data(), out);
+    // the constant columns are the first num_constants columns of the host matrix; the sigma columns come from the classes
+    return gl_circuit_create_from_classes(ctx, &hc->hc.desc, hc->hc.constants_sigmas.data(), hc->hc.wire_class.data(), out);
+}
+extern "C" int gl_host_circuit_wire_classes(const gl_host_circuit* hc, uint64_t* h_out) {
+    GL_REQUIRE(hc && h_out, GL_ERR_ARG, "null argument");
+    memcpy(h_out, hc->hc.wire_class.data(), hc->hc.wire_class.size() * sizeof(uint64_t));
+    return GL_OK;
 }
 extern "C" int gl_circuit_digest(const gl_circuit* c, uint64_t h_out[4]) {
     GL_REQUIRE(c && h_out, GL_ERR_ARG, "null argument");
@@ -185,14 +225,6 @@ static void put_u64(std::vector<uint8_t>& o, uint64_t v) { for (int i = 0; i < 8
 static void put_words(std::vector<uint8_t>& o, const gl_t* v, size_t n) { for (size_t i = 0; i < n; i++) put_u64(o, gl_canon(v[i])); }
 static uint32_t host_bitrev32(uint32_t x, uint32_t bits) { uint32_t r = 0; for (uint32_t i = 0; i < bits; i++) r = (r << 1) | ((x >> i) & 1); return r; }
 
-struct DevBuf {                     // RAII block from the context's stream-ordered pool
-    gl_ctx* c; void* p = nullptr;
-    explicit DevBuf(gl_ctx* ctx) : c(ctx) {}
-    int alloc(size_t bytes) { return c->pool_alloc(bytes, &p); }
-    void release() { if (p) { c->pool_release(p); p = nullptr; } }
-    ~DevBuf() { release(); }
-    template <class T> T* as() const { return (T*)p; }
-};
 struct BatchHolder { gl_batch* b = nullptr; ~BatchHolder() { if (b) gl_batch_free(b); } };
 struct MerkleHolder { gl_ctx* c; GlMerkle m; explicit MerkleHolder(gl_ctx* ctx) : c(ctx) {} ~MerkleHolder() { gl_merkle_release(c, &m); } };
 

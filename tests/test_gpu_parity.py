@@ -775,3 +775,42 @@ def test_handles_may_outlive_and_be_freed_after_their_context(gpu):
     r = subprocess.run([sys.executable, "-c", _LIFETIME_SCRIPT % root], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert "lifetime ok" in r.stdout
+
+
+# ------------------------------------------------------------------------------------------ build(): sigma polynomials on the device
+@pytest.mark.parametrize("m", [1, 2, 5, 20, 64])
+def test_device_sigma_polynomials_equal_the_host_and_oracle_ones(gpu, orc, m):
+    # gl_circuit_from_host computes the 80 sigma polynomials on the GPU from the copy-constraint classes (sigma.hip: one
+    # stable radix sort instead of the reference's union-find forest, circuit_builder.rs:1007-1014); the host columns
+    # (gl_host_circuit_constants_sigmas, the closed-form restatement) through gl_circuit_create must give the same
+    # commitment and digest, and both must equal the oracle's (generic builder + forest)
+    import ctypes
+    from plonky2_demo_amd import api, _lib
+    from plonky2_demo_amd._lib import check, lib
+    p, ctx = gpu
+    hc = p.MatmulCircuit(m)
+    dev = hc.build(ctx)                                                   # sigma on the device
+    host = p.GenericCircuitData(hc.desc, hc.constants_sigmas(), ctx=ctx)  # sigma columns from the host
+    oc = orc.circuit(m, threads=4)
+    assert (dev.circuit_digest == host.circuit_digest).all() and (dev.circuit_digest == oc.digest).all()
+    assert (dev.constants_sigmas_cap == host.constants_sigmas_cap).all() and (dev.constants_sigmas_cap == oc.constants_sigmas_cap).all()
+    assert (dev.constants_sigmas_batch.polynomials == host_batch_polys(p, hc, ctx)).all()
+    # the class ids are only compared for equality: relabelling them (an affine bijection here) changes nothing
+    cls = np.empty((80, hc.n), dtype=np.uint64)
+    check(lib.gl_host_circuit_wire_classes(hc.handle, cls.ctypes.data_as(ctypes.c_void_p)))
+    relabel = (cls * np.uint64(6364136223846793005) + np.uint64(1442695040888963407))      # odd multiplier: a bijection mod 2^64
+    consts = np.ascontiguousarray(hc.constants_sigmas()[: hc.desc.num_constants])
+    h = ctypes.c_void_p()
+    check(lib.gl_circuit_create_from_classes(ctx.handle, ctypes.byref(hc.desc), consts.ctypes.data_as(ctypes.c_void_p),
+                                             relabel.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)))
+    try:
+        dig = np.empty(4, dtype=np.uint64)
+        check(lib.gl_circuit_digest(h, dig.ctypes.data_as(ctypes.c_void_p)))
+        assert (dig == oc.digest).all()
+    finally:
+        lib.gl_circuit_free(h)
+
+
+def host_batch_polys(p, hc, ctx):
+    cs = hc.constants_sigmas()
+    return p.PolynomialBatch.from_values(cs, 3, False, 4, ctx=ctx).polynomials
