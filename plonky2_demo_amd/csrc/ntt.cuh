@@ -23,8 +23,11 @@
 #include "gl64_gfx950.cuh"
 
 #define NTT_TILE_LOG 13                 // elements per workgroup tile (8192 * 8 B = 64 KiB of LDS)
-#define NTT_THREADS 512
-#define NTT_EPT ((1 << NTT_TILE_LOG) / NTT_THREADS)   // 32 elements per thread
+#ifndef NTT_THREADS
+#define NTT_THREADS 512                 // 512: 16 elements per thread, radix-16 register blocks, 4 waves per SIMD (2 workgroups per CU);
+#endif                                  // 1024: 8 per thread, radix-8 blocks, 8 waves per SIMD when the kernel fits 64 VGPRs
+#define NTT_EPT ((1 << NTT_TILE_LOG) / NTT_THREADS)   // elements per thread
+#define NTT_WAVES_PER_SIMD (NTT_THREADS / 64 / 4 * 2)  // two workgroups per CU (LDS)
 #define NTT_LOCAL_MAX_LOG 12            // largest in-LDS transform
 #ifdef NTT_ABLATION
 #define NTT_DBG(p, bit) ((p).debug & (bit))
@@ -53,7 +56,8 @@ struct NttPassParams {
 };
 
 __host__ __device__ constexpr int ntt_first_radix(int rem) {
-    return rem <= 4 ? rem : (rem == 5 || rem == 6 || rem == 9) ? 3 : 4;
+    if (NTT_EPT >= 16) return rem <= 4 ? rem : (rem == 5 || rem == 6 || rem == 9) ? 3 : 4;
+    return rem <= 3 ? rem : (rem == 4 ? 2 : 3);          // radix at most 8: 10 = 3 + 3 + 2 + 2
 }
 __host__ __device__ constexpr unsigned ntt_bitrev(unsigned x, int bits) {
     unsigned r = 0;
@@ -151,7 +155,7 @@ __device__ __forceinline__ gl_t ntt_pow2level(const gl_t* lo, const gl_t* hi, ui
 template <int LOGL>
 struct NttGeom {
     static constexpr int LOGT = NTT_TILE_LOG - LOGL, T = 1 << LOGT, L = 1 << LOGL;
-    static constexpr bool WAVE_OWNED = (LOGL <= 10);
+    static constexpr bool WAVE_OWNED = ((1 << LOGL) <= 64 * NTT_EPT);          // a wave (64 lanes x NTT_EPT elements) holds whole columns
     static constexpr int LW = L + (L >> 4) + (T >= 32 ? 1 : 32 / T);           // column stride (elements), see at()
     static constexpr int LDT = T + 1;                                          // row stride of the legacy layout
     static constexpr size_t LDS_BYTES = WAVE_OWNED ? (size_t)T * LW * 8 : (size_t)L * LDT * 8;
@@ -255,7 +259,7 @@ __device__ __forceinline__ void ntt_st(gl_t* base, uint32_t i, gl_t x) { *(gl_t*
 
 // COLUMN pass (pass A).  grid = (N2 / T, batch).
 template <int LOGL, bool INV, bool ZP = false>
-__global__ __launch_bounds__(NTT_THREADS, 4) void ntt_col_pass(NttPassParams p) {
+__global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_col_pass(NttPassParams p) {
     using G = NttGeom<LOGL>;
     constexpr int LOGT = G::LOGT, T = G::T;
     extern __shared__ __align__(16) gl_t lds[];
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_col_pass(NttPassParams p) 
 //   two-pass:   grid = (N1 / T, batch): rows k1 of one polynomial
 //   single:     grid = (ceil(batch / T), 1): T polynomials
 template <int LOGL, bool INV, bool SINGLE>
-__global__ __launch_bounds__(NTT_THREADS, 4) void ntt_row_pass(NttPassParams p) {
+__global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_row_pass(NttPassParams p) {
     using G = NttGeom<LOGL>;
     constexpr int LOGT = G::LOGT, T = G::T, L = G::L;
     extern __shared__ __align__(16) gl_t lds[];

@@ -6,11 +6,14 @@ set -e
 cd "$(dirname "$0")/.."
 CS=plonky2_demo_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=off -DNTT_ABLATION -c $CS/ntt.hip -o /tmp/ntt_abl.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libplonky2_mi355x_ablation.so /tmp/ntt_abl.o $CS/batch.o $CS/merkle.o $CS/prove.o $CS/verifier.o $CS/witness.o $CS/serialization.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libplonky2_mi355x_ablation.so /tmp/ntt_abl.o $(ls $CS/*.o | grep -v "/ntt.o")
 export PLONKY2_MI355X_LIB=/tmp/libplonky2_mi355x_ablation.so
-for mode in 0 1 3 5 7; do
+for mode in 0 6 2 4 1 3 5 7; do
   case $mode in
     0) what="full kernels";;
+    6) what="butterfly stages only: no global loads, no global stores (the VALU phase)";;
+    2) what="no global loads";;
+    4) what="no global stores";;
     1) what="no butterfly stages (global load, LDS transpose, inter-pass twiddle multiply, global store)";;
     3) what="no stages, no global loads (LDS + twiddle multiply + stores)";;
     5) what="no stages, no global stores (loads + LDS + twiddle multiply)";;
