@@ -274,34 +274,34 @@ __device__ __forceinline__ gl_t glx_sub_cc(gl_t a, gl_t b) {                    
     const gl_t d = a - b;
     return d - ((a < b) ? GL_EPS : 0);
 #endif
-    uint32_t r0 = (uint32_t)a, r1 = (uint32_t)(a >> 32), e;
-    asm("v_sub_co_u32 %[r0], vcc, %[r0], %[b0]\n\t"
+    // (outputs are NOT tied to a: a butterfly still needs a for a + b, and a tied operand would cost two register copies)
+    uint32_t r0, r1, e;
+    asm("v_sub_co_u32 %[r0], vcc, %[a0], %[b0]\n\t"
         "s_nop 1\n\t"
-        "v_subb_co_u32 %[r1], vcc, %[r1], %[b1], vcc\n\t"
+        "v_subb_co_u32 %[r1], vcc, %[a1], %[b1], vcc\n\t"
         "s_nop 1\n\t"
         "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"                        // borrow: + p = - EPS (mod 2^64)
         "v_sub_co_u32 %[r0], vcc, %[r0], %[e]\n\t"
         "s_nop 1\n\t"
         "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc"
-        : [r0] "+v"(r0), [r1] "+v"(r1), [e] "=&v"(e)
-        : [b0] "v"((uint32_t)b), [b1] "v"((uint32_t)(b >> 32))
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [e] "=&v"(e)
+        : [a0] "v"((uint32_t)a), [a1] "v"((uint32_t)(a >> 32)), [b0] "v"((uint32_t)b), [b1] "v"((uint32_t)(b >> 32))
         : "vcc");
     return glx_mk64(r0, r1);
 }
 // four canonical differences at once: the borrow chains of four independent subtractions interleave, no wait states
 __device__ __forceinline__ void glx_sub_cc4(const gl_t (&a)[4], const gl_t (&b)[4], gl_t (&r)[4]) {
     typedef uint32_t u32;
-    u32 r0A = (u32)a[0], r1A = (u32)(a[0] >> 32), r0B = (u32)a[1], r1B = (u32)(a[1] >> 32), r0C = (u32)a[2], r1C = (u32)(a[2] >> 32), r0D = (u32)a[3], r1D = (u32)(a[3] >> 32);
-    u32 eA, eB, eC, eD;
+    u32 r0A, r1A, r0B, r1B, r0C, r1C, r0D, r1D, eA, eB, eC, eD;
     uint64_t sB, sC, sD;
-    asm("v_sub_co_u32 %[r0A], vcc, %[r0A], %[b0A]\n\t"
-        "v_sub_co_u32_e64 %[r0B], %[sB], %[r0B], %[b0B]\n\t"
-        "v_sub_co_u32_e64 %[r0C], %[sC], %[r0C], %[b0C]\n\t"
-        "v_sub_co_u32_e64 %[r0D], %[sD], %[r0D], %[b0D]\n\t"
-        "v_subb_co_u32 %[r1A], vcc, %[r1A], %[b1A], vcc\n\t"
-        "v_subb_co_u32_e64 %[r1B], %[sB], %[r1B], %[b1B], %[sB]\n\t"
-        "v_subb_co_u32_e64 %[r1C], %[sC], %[r1C], %[b1C], %[sC]\n\t"
-        "v_subb_co_u32_e64 %[r1D], %[sD], %[r1D], %[b1D], %[sD]\n\t"
+    asm("v_sub_co_u32 %[r0A], vcc, %[a0A], %[b0A]\n\t"
+        "v_sub_co_u32_e64 %[r0B], %[sB], %[a0B], %[b0B]\n\t"
+        "v_sub_co_u32_e64 %[r0C], %[sC], %[a0C], %[b0C]\n\t"
+        "v_sub_co_u32_e64 %[r0D], %[sD], %[a0D], %[b0D]\n\t"
+        "v_subb_co_u32 %[r1A], vcc, %[a1A], %[b1A], vcc\n\t"
+        "v_subb_co_u32_e64 %[r1B], %[sB], %[a1B], %[b1B], %[sB]\n\t"
+        "v_subb_co_u32_e64 %[r1C], %[sC], %[a1C], %[b1C], %[sC]\n\t"
+        "v_subb_co_u32_e64 %[r1D], %[sD], %[a1D], %[b1D], %[sD]\n\t"
         "v_cndmask_b32_e64 %[eA], 0, -1, vcc\n\t"                       // borrow: + p = - EPS (mod 2^64)
         "v_cndmask_b32_e64 %[eB], 0, -1, %[sB]\n\t"
         "v_cndmask_b32_e64 %[eC], 0, -1, %[sC]\n\t"
@@ -314,9 +314,11 @@ __device__ __forceinline__ void glx_sub_cc4(const gl_t (&a)[4], const gl_t (&b)[
         "v_subbrev_co_u32_e64 %[r1B], %[sB], 0, %[r1B], %[sB]\n\t"
         "v_subbrev_co_u32_e64 %[r1C], %[sC], 0, %[r1C], %[sC]\n\t"
         "v_subbrev_co_u32_e64 %[r1D], %[sD], 0, %[r1D], %[sD]"
-        : [r0A] "+v"(r0A), [r1A] "+v"(r1A), [r0B] "+v"(r0B), [r1B] "+v"(r1B), [r0C] "+v"(r0C), [r1C] "+v"(r1C), [r0D] "+v"(r0D), [r1D] "+v"(r1D),
+        : [r0A] "=&v"(r0A), [r1A] "=&v"(r1A), [r0B] "=&v"(r0B), [r1B] "=&v"(r1B), [r0C] "=&v"(r0C), [r1C] "=&v"(r1C), [r0D] "=&v"(r0D), [r1D] "=&v"(r1D),
           [eA] "=&v"(eA), [eB] "=&v"(eB), [eC] "=&v"(eC), [eD] "=&v"(eD), [sB] "=&s"(sB), [sC] "=&s"(sC), [sD] "=&s"(sD)
-        : [b0A] "v"((u32)b[0]), [b1A] "v"((u32)(b[0] >> 32)), [b0B] "v"((u32)b[1]), [b1B] "v"((u32)(b[1] >> 32)),
+        : [a0A] "v"((u32)a[0]), [a1A] "v"((u32)(a[0] >> 32)), [a0B] "v"((u32)a[1]), [a1B] "v"((u32)(a[1] >> 32)),
+          [a0C] "v"((u32)a[2]), [a1C] "v"((u32)(a[2] >> 32)), [a0D] "v"((u32)a[3]), [a1D] "v"((u32)(a[3] >> 32)),
+          [b0A] "v"((u32)b[0]), [b1A] "v"((u32)(b[0] >> 32)), [b0B] "v"((u32)b[1]), [b1B] "v"((u32)(b[1] >> 32)),
           [b0C] "v"((u32)b[2]), [b1C] "v"((u32)(b[2] >> 32)), [b0D] "v"((u32)b[3]), [b1D] "v"((u32)(b[3] >> 32))
         : "vcc");
     r[0] = glx_mk64(r0A, r1A); r[1] = glx_mk64(r0B, r1B); r[2] = glx_mk64(r0C, r1C); r[3] = glx_mk64(r0D, r1D);
