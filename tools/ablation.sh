@@ -20,5 +20,5 @@ for mode in 0 6 2 4 1 3 5 7; do
     7) what="no stages, loads or stores (LDS traffic and the twiddle multiply only)";;
   esac
   echo "== GL_NTT_DEBUG=$mode: $what"
-  GL_NTT_DEBUG=$mode python3 tools/time_ntt.py 20 64 5 2>&1 | grep -E "pass\(forward|^forward"
+  GL_NTT_DEBUG=$mode python3 tools/time_ntt.py 20 64 40 2>&1 | grep -E "pass\(forward|^forward"
 done

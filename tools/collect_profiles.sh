@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/kt_prove -o kt --output-format csv -- p
 cp $OUT/kt_prove/kt_kernel_stats.csv $OUT/${R}_bench_prove_m64_kernel_stats.csv
 python3 $ROOT/tools/busy.py $OUT/kt_prove/kt_kernel_trace.csv 0.5 > $OUT/${R}_bench_prove_m64_gpu_busy.txt
 echo "[3] kernel stats of the 2^20 NTT x 64"
-rocprofv3 --kernel-trace --stats -d $OUT/kt_ntt -o kt --output-format csv -- python3 $ROOT/tools/prof_ntt.py 64 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt_ntt -o kt --output-format csv -- python3 $ROOT/tools/prof_ntt.py 64 40 > /dev/null 2>&1
 cp $OUT/kt_ntt/kt_kernel_stats.csv $OUT/${R}_ntt20_kernel_stats.csv
 echo "[4] HBM traffic of the forward NTT (separate FETCH_SIZE / WRITE_SIZE passes)"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- python3 $ROOT/tools/prof_traffic.py 64 3 > /dev/null 2>&1

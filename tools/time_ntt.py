@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Device time of the forward / inverse 2^lg NTT over a batch (HIP events per launch): python tools/time_ntt.py [lg=20] [batch=64] [reps=5]"""
+"""Device time of the forward / inverse 2^lg NTT over a batch (HIP events per launch): python tools/time_ntt.py [lg=20] [batch=64] [reps=40]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,7 +8,7 @@ import plonky2_demo_amd as p
 from plonky2_demo_amd._lib import check, lib
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 40      # a cold GPU needs tens of ms of work to reach its clocks: 5 repetitions read ~12 % slow
 ctx = p.default_context()
 if len(sys.argv) > 4:
     ctx.set_scratch_elems(1 << int(sys.argv[4]))      # inter-pass scratch (elements): chunk = scratch / 2^lg polynomials
