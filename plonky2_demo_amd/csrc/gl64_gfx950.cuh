@@ -395,6 +395,54 @@ __device__ __forceinline__ gl_t glx_shl_c(gl_t x) {
         return glx_sub_cc(le, hm);
     }
 }
+// ---- sums of products without a reduction per term: the quotient's alpha-weighted constraint sums --------------------------
+// sum_t term_t * alpha_t for TWO weight sequences (the two challenges alpha) kept as three 64-bit partial sums of 32 x 32-bit
+// products each (weights 1, 2^32, 2^64) plus the number of times each wrapped: 16 instructions per term for both sums -- a
+// modular multiply-add each would be 2 x ~21 -- and one reduction at the end.  Terms may be any u64 representatives; the
+// weights must be wave-uniform (they are read as scalar operands).
+struct GlxWideAcc2 {
+    gl_t a0[2], a1[2], a2[2];       // sum t0*w0 | sum (t0*w1 + t1*w0) | sum t1*w1       (mod 2^64)
+    uint32_t k0[2], k1[2], k2[2];   // wrap counts of the three sums (each worth 2^64 of its weight)
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int b = 0; b < 2; b++) { a0[b] = 0; a1[b] = 0; a2[b] = 0; k0[b] = 0; k1[b] = 0; k2[b] = 0; }
+    }
+    __device__ __forceinline__ void mac(gl_t term, gl_t wA, gl_t wB) {
+        typedef uint32_t u32;
+        uint64_t c0, c1, c2, c3, c4, c5;
+        // the carry of every multiply-add is consumed at least three instructions later: no wait states
+        asm("v_mad_u64_u32 %[a0A], %[c0], %[t0], %[wA0], %[a0A]\n\t"
+            "v_mad_u64_u32 %[a0B], %[c1], %[t0], %[wB0], %[a0B]\n\t"
+            "v_mad_u64_u32 %[a1A], %[c2], %[t0], %[wA1], %[a1A]\n\t"
+            "v_mad_u64_u32 %[a1B], %[c3], %[t0], %[wB1], %[a1B]\n\t"
+            "v_mad_u64_u32 %[a2A], %[c4], %[t1], %[wA1], %[a2A]\n\t"
+            "v_mad_u64_u32 %[a2B], %[c5], %[t1], %[wB1], %[a2B]\n\t"
+            "v_addc_co_u32_e64 %[k0A], vcc, 0, %[k0A], %[c0]\n\t"
+            "v_addc_co_u32_e64 %[k0B], vcc, 0, %[k0B], %[c1]\n\t"
+            "v_addc_co_u32_e64 %[k1A], vcc, 0, %[k1A], %[c2]\n\t"
+            "v_addc_co_u32_e64 %[k1B], vcc, 0, %[k1B], %[c3]\n\t"
+            "v_mad_u64_u32 %[a1A], %[c0], %[t1], %[wA0], %[a1A]\n\t"
+            "v_mad_u64_u32 %[a1B], %[c1], %[t1], %[wB0], %[a1B]\n\t"
+            "v_addc_co_u32_e64 %[k2A], vcc, 0, %[k2A], %[c4]\n\t"
+            "v_addc_co_u32_e64 %[k2B], vcc, 0, %[k2B], %[c5]\n\t"
+            "v_addc_co_u32_e64 %[k1A], vcc, 0, %[k1A], %[c0]\n\t"
+            "v_addc_co_u32_e64 %[k1B], vcc, 0, %[k1B], %[c1]"
+            : [a0A] "+v"(a0[0]), [a1A] "+v"(a1[0]), [a2A] "+v"(a2[0]), [k0A] "+v"(k0[0]), [k1A] "+v"(k1[0]), [k2A] "+v"(k2[0]),
+              [a0B] "+v"(a0[1]), [a1B] "+v"(a1[1]), [a2B] "+v"(a2[1]), [k0B] "+v"(k0[1]), [k1B] "+v"(k1[1]), [k2B] "+v"(k2[1]),
+              [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [c4] "=&s"(c4), [c5] "=&s"(c5)
+            : [t0] "v"((u32)term), [t1] "v"((u32)(term >> 32)),
+              [wA0] "s"((u32)wA), [wA1] "s"((u32)(wA >> 32)), [wB0] "s"((u32)wB), [wB1] "s"((u32)(wB >> 32))
+            : "vcc");
+    }
+    // canonical value of sum b:  a0 + a1 2^32 + (a2 + k0) 2^64 + k1 2^96 + k2 2^128,  2^64 = EPS, 2^96 = -1, 2^128 = -2^32 (mod p)
+    __device__ __forceinline__ gl_t sum(int b) const {
+        gl_t r = glx_add_cc(glx_canon(a0[b]), glx_shl_c<32>(glx_canon(a1[b])));
+        r = glx_add_cc(r, glx_shl_c<64>(glx_canon(a2[b])));
+        r = glx_add_cc(r, glx_shl_c<64>((gl_t)k0[b]));
+        r = glx_sub_cc(r, (gl_t)k1[b]);
+        return glx_sub_cc(r, glx_shl_c<32>((gl_t)k2[b]));
+    }
+};
 #elif defined(__HIPCC__)
 // host pass of a .hip file: kernels that call these must still parse
 template <bool CANON>
@@ -411,4 +459,11 @@ template <int E>
 __device__ gl_t glx_shl_c(gl_t x);
 __device__ gl_t glx_acc_reduce(gl_t al, gl_t ah);
 __device__ void glx_acc_reduce3(gl_t alA, gl_t ahA, gl_t alB, gl_t ahB, gl_t alC, gl_t ahC, gl_t& rA, gl_t& rB, gl_t& rC);
+struct GlxWideAcc2 {
+    gl_t a0[2], a1[2], a2[2];
+    uint32_t k0[2], k1[2], k2[2];
+    __device__ void clear();
+    __device__ void mac(gl_t term, gl_t wA, gl_t wB);
+    __device__ gl_t sum(int b) const;
+};
 #endif

@@ -172,14 +172,14 @@ struct GlQuotParams {
 };
 #define GLQ_MAX_TERMS 152
 
-// running alpha-weighted sums for the two alphas
+// running alpha-weighted sums for the two alphas: unreduced (GlxWideAcc2: 16 instructions per term for both), one reduction
+// when the sum is used
 struct GlAlphaAcc {
-    gl_t s0, s1;
-    const gl_t* ap;             // alpha_pows base
-    __device__ __forceinline__ void add(uint32_t t, gl_t term) {
-        s0 = gl_mul_add(s0, term, ap[t]);
-        s1 = gl_mul_add(s1, term, ap[GLQ_MAX_TERMS + t]);
-    }
+    GlxWideAcc2 w;
+    const gl_t* ap;             // alpha_pows base (uniform: the weights are scalar operands)
+    __device__ __forceinline__ void start(const gl_t* alpha_pows) { w.clear(); ap = alpha_pows; }
+    __device__ __forceinline__ void add(uint32_t t, gl_t term) { w.mac(term, ap[t], ap[GLQ_MAX_TERMS + t]); }
+    __device__ __forceinline__ gl_t sum(int b) const { return w.sum(b); }
 };
 
 // PoseidonGate constraints (gates/poseidon.rs:193-272), term index base `t0`.  Wire k of the point lives at w[k * N]; the
@@ -277,18 +277,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     const gl_t* w = p.wires + i;
     const gl_t* cs = p.cs + i;
     const gl_t* zs = p.zs + i;
-    GlAlphaAcc total; total.s0 = 0; total.s1 = 0; total.ap = p.alpha_pows;
+    // every operand read below is canonical: LDE values and tables are written by the NTT / table kernels, which store
+    // canonical words, and the challenges come from the transcript
+    GlAlphaAcc terms; terms.start(p.alpha_pows);
+    gl_t tot0 = 0, tot1 = 0;                                         // canonical running totals
     if constexpr (!POSEIDON_PART) {
-    const gl_t x = glp_pow2level(p.xpow_lo, p.xpow_hi, i);          // 7 * w^i
+    const gl_t x = glx_canon(glp_pow2level(p.xpow_lo, p.xpow_hi, i));          // 7 * w^i
     const uint32_t i_next = (i + p.next_step) & (uint32_t)(N - 1);
     // L_0(x) (Z(x) - 1)            (vanishing_poly.rs:263-268; zero_poly_coset.rs:55-60)
     const gl_t l0 = p.l0_coset[i];
-    total.add(0, gl_mul(l0, gl_sub(zs[0], 1)));
-    total.add(1, gl_mul(l0, gl_sub(zs[N], 1)));
+    gl_t bx0, bx1, lz0, lz1, bxk0, bxk1, unused;
+    glx_mul3<true>(p.betas[0], x, p.betas[1], x, l0, glx_sub_cc(zs[0], 1), bx0, bx1, lz0);
+    terms.add(0, lz0);
+    glx_mul3<true>(bx0, p.k_is[0], bx1, p.k_is[0], l0, glx_sub_cc(zs[N], 1), bxk0, bxk1, lz1);   // beta x k_j: a running x7 when k_j = 7^j
+    terms.add(1, lz1);
     // partial-product checks (util/partial_products.rs:52-76): terms 2 + 10 a + c
     {
-        gl_t bx0 = gl_mul(p.betas[0], x), bx1 = gl_mul(p.betas[1], x);
-        gl_t bxk0 = gl_mul(bx0, p.k_is[0]), bxk1 = gl_mul(bx1, p.k_is[0]);   // beta x k_j: a running x7 when k_j = 7^j
+        const gl_t beta0 = p.betas[0], beta1 = p.betas[1], gamma0 = p.gammas[0], gamma1 = p.gammas[1];
         gl_t prev0 = zs[0], prev1 = zs[N];
 #pragma unroll 1
         for (int c = 0; c < GLP_CHUNKS; c++) {
@@ -297,20 +302,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
             for (int q = 0; q < 8; q++) {
                 const int j = c * 8 + q;
                 const gl_t wv = w[(size_t)j * N], sg = cs[(size_t)(p.num_constants + j) * N];
-                if (!p.k_is_powers_of_7) { const gl_t k = p.k_is[j]; bxk0 = gl_mul(bx0, k); bxk1 = gl_mul(bx1, k); }
-                n0 = gl_mul(n0, gl_add(gl_add(wv, bxk0), p.gammas[0]));
-                d0 = gl_mul(d0, gl_add(gl_mul_add(wv, p.betas[0], sg), p.gammas[0]));
-                n1 = gl_mul(n1, gl_add(gl_add(wv, bxk1), p.gammas[1]));
-                d1 = gl_mul(d1, gl_add(gl_mul_add(wv, p.betas[1], sg), p.gammas[1]));
-                if (p.k_is_powers_of_7) { bxk0 = gl_mul_small(bxk0, 7); bxk1 = gl_mul_small(bxk1, 7); }
+                if (!p.k_is_powers_of_7) { const gl_t k = p.k_is[j]; glx_mul3<true>(bx0, k, bx1, k, 0, 0, bxk0, bxk1, unused); }
+                // numerator factor w + beta k_j x + gamma, denominator factor w + beta sigma_j(x) + gamma; six products per
+                // wire, three at a time (the carry chains of three independent products interleave)
+                const gl_t f0 = glx_add_cc(glx_add_cc(wv, bxk0), gamma0), f1 = glx_add_cc(glx_add_cc(wv, bxk1), gamma1);
+                gl_t sb0, sb1;
+                glx_mul3<true>(sg, beta0, sg, beta1, n0, f0, sb0, sb1, n0);
+                const gl_t g0 = glx_add_cc(glx_add_cc(wv, sb0), gamma0), g1 = glx_add_cc(glx_add_cc(wv, sb1), gamma1);
+                glx_mul3<true>(d0, g0, n1, f1, d1, g1, d0, n1, d1);
+                if (p.k_is_powers_of_7) {                             // 7 y = 8 y - y
+                    bxk0 = glx_sub_cc(glx_shl_c<3>(bxk0), bxk0); bxk1 = glx_sub_cc(glx_shl_c<3>(bxk1), bxk1);
+                }
             }
             const gl_t next0 = (c == GLP_CHUNKS - 1) ? p.zs[i_next] : zs[(size_t)(2 + c) * N];
             const gl_t next1 = (c == GLP_CHUNKS - 1) ? p.zs[N + i_next] : zs[(size_t)(2 + (GLP_CHUNKS - 1) + c) * N];
-            total.add(2 + c, gl_sub(gl_mul(prev0, n0), gl_mul(next0, d0)));
-            total.add(2 + GLP_CHUNKS + c, gl_sub(gl_mul(prev1, n1), gl_mul(next1, d1)));
+            gl_t pn0, nd0, pn1, nd1;
+            glx_mul3<true>(prev0, n0, next0, d0, prev1, n1, pn0, nd0, pn1);
+            nd1 = glx_mul<true>(next1, d1);
+            terms.add(2 + c, glx_sub_cc(pn0, nd0));
+            terms.add(2 + GLP_CHUNKS + c, glx_sub_cc(pn1, nd1));
             prev0 = next0; prev1 = next1;
         }
     }
+    tot0 = terms.sum(0); tot1 = terms.sum(1);
     }
     // gate constraints: sum_g filter_g * sum_j alpha^(22+j) c_{g,j}   (vanishing_poly.rs:706-732, gate.rs:121-146)
     const uint32_t T0 = 2 + 2 * GLP_CHUNKS;
@@ -320,41 +334,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
         if ((p.gate_types[g] == 4) != POSEIDON_PART) continue;
         const gl_t sel = cs[(size_t)p.gate_sel[g] * N];
         gl_t filter = 1;                                            // gate.rs:277-284
-        for (uint32_t k = p.group_start[g]; k < p.group_end[g]; k++) if (k != g) filter = gl_mul(filter, gl_sub((gl_t)k, sel));
-        if (p.num_selectors > 1) filter = gl_mul(filter, gl_sub((gl_t)0xFFFFFFFFull, sel));
-        GlAlphaAcc acc; acc.s0 = 0; acc.s1 = 0; acc.ap = p.alpha_pows;
+        for (uint32_t k = p.group_start[g]; k < p.group_end[g]; k++) if (k != g) filter = glx_mul<true>(filter, glx_sub_cc((gl_t)k, sel));
+        if (p.num_selectors > 1) filter = glx_mul<true>(filter, glx_sub_cc((gl_t)0xFFFFFFFFull, sel));
+        GlAlphaAcc acc; acc.start(p.alpha_pows);
         if constexpr (POSEIDON_PART) glq_poseidon_gate(w, N, acc, T0);
         else switch (p.gate_types[g]) {
             case 1:     // ConstantGate (gates/constant.rs:59-66)
-                acc.add(T0, gl_sub(gc[0], w[0]));
-                acc.add(T0 + 1, gl_sub(gc[N], w[N]));
+                acc.add(T0, glx_sub_cc(gc[0], w[0]));
+                acc.add(T0 + 1, glx_sub_cc(gc[N], w[N]));
                 break;
             case 2:     // PublicInputGate (gates/public_input.rs:44-49)
 #pragma unroll
-                for (int k = 0; k < 4; k++) acc.add(T0 + k, gl_sub(w[(size_t)k * N], p.pi_hash[k]));
+                for (int k = 0; k < 4; k++) acc.add(T0 + k, glx_sub_cc(w[(size_t)k * N], p.pi_hash[k]));
                 break;
-            case 3: {   // ArithmeticGate (gates/arithmetic_base.rs:163-181)
+            case 3: {   // ArithmeticGate (gates/arithmetic_base.rs:163-181): two operations at a time, six products in two groups
                 const gl_t c0 = gc[0], c1 = gc[N];
-#pragma unroll 4
-                for (int k = 0; k < 20; k++) {
-                    const gl_t m0 = w[(size_t)(4 * k) * N], m1 = w[(size_t)(4 * k + 1) * N], ad = w[(size_t)(4 * k + 2) * N], o = w[(size_t)(4 * k + 3) * N];
-                    const gl_t computed = gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(ad, c1));
-                    acc.add(T0 + k, gl_sub(o, computed));
+#pragma unroll 2
+                for (int k = 0; k < 20; k += 2) {
+                    const gl_t* wk = w + (size_t)(4 * k) * N;
+                    const gl_t m0a = wk[0], m1a = wk[N], ada = wk[2 * N], oa = wk[3 * N], m0b = wk[4 * N], m1b = wk[5 * N], adb = wk[6 * N], ob = wk[7 * N];
+                    gl_t pa, pb, qa, qb;
+                    glx_mul3<true>(m0a, m1a, m0b, m1b, ada, c1, pa, pb, qa);
+                    glx_mul3<true>(pa, c0, pb, c0, adb, c1, pa, pb, qb);
+                    acc.add(T0 + k, glx_sub_cc(oa, glx_add_cc(pa, qa)));
+                    acc.add(T0 + k + 1, glx_sub_cc(ob, glx_add_cc(pb, qb)));
                 }
                 break;
             }
             default: break;   // NoopGate
         }
-        total.s0 = gl_mul_add(total.s0, filter, acc.s0);
-        total.s1 = gl_mul_add(total.s1, filter, acc.s1);
+        gl_t fs0, fs1, unused;
+        glx_mul3<true>(filter, acc.sum(0), filter, acc.sum(1), 0, 0, fs0, fs1, unused);
+        tot0 = glx_add_cc(tot0, fs0); tot1 = glx_add_cc(tot1, fs1);
     }
     const gl_t zi = p.zh_inv[i & 7];
-    if constexpr (POSEIDON_PART) {
-        p.out[i] = gl_canon(gl_mul_add(p.out[i], total.s0, zi));
-        p.out[N + i] = gl_canon(gl_mul_add(p.out[N + i], total.s1, zi));
+    gl_t o0, o1, unused;
+    glx_mul3<true>(tot0, zi, tot1, zi, 0, 0, o0, o1, unused);
+    if constexpr (POSEIDON_PART) {                                   // (the other launch wrote canonical words)
+        p.out[i] = glx_add_cc(p.out[i], o0);
+        p.out[N + i] = glx_add_cc(p.out[N + i], o1);
     } else {
-        p.out[i] = gl_canon(gl_mul(total.s0, zi));
-        p.out[N + i] = gl_canon(gl_mul(total.s1, zi));
+        p.out[i] = o0;
+        p.out[N + i] = o1;
     }
 }
 
@@ -555,20 +576,26 @@ __global__ __launch_bounds__(256) void k_fri_fold(const gl_t* ia, const gl_t* ib
 }
 
 // ---- proof of work: smallest w >= base with clz(permute(state with w at pos)[7]) >= bits ----------------------------------
+// A grid of about 2^bits / 2 lanes (gl_pow_grind) walks the window in ascending sweeps and every lane stops as soon as a
+// witness below its next candidate is known, so about 2^bits + one sweep candidates are hashed (a whole-window launch hashes the
+// full window: 2.3 x 2^bits for a window of 2 x 2^bits).  The minimum is exact: a lane only skips candidates above a witness
+// that has already been found.  Every lane leaves the loop after at most count / (gridDim.x * blockDim.x) + 1 iterations.
 struct GlPowParams { gl_t state[12]; uint32_t pos, min_leading_zeros; uint64_t base, count; unsigned long long* result; };
 __global__ __launch_bounds__(256) void k_pow_grind(GlPowParams p) {
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.count) return;
-    const uint64_t cand = p.base + idx;
-    gl_t s[12];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < p.count; idx += stride) {
+        const uint64_t cand = p.base + idx;
+        if (__hip_atomic_load(p.result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cand) break;
+        gl_t s[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = p.state[i];
+        for (int i = 0; i < 12; i++) s[i] = p.state[i];
 #pragma unroll
-    for (int i = 0; i < 8; i++) if ((uint32_t)i == p.pos) s[i] = cand;
-    psd_permute(s);
-    const gl_t r = gl_canon(s[7]);
-    const uint32_t lz = r ? (uint32_t)__clzll((long long)r) : 64u;
-    if (lz >= p.min_leading_zeros) atomicMin(p.result, (unsigned long long)cand);
+        for (int i = 0; i < 8; i++) if ((uint32_t)i == p.pos) s[i] = cand;
+        psd_permute(s);
+        const gl_t r = gl_canon(s[7]);
+        const uint32_t lz = r ? (uint32_t)__clzll((long long)r) : 64u;
+        if (lz >= p.min_leading_zeros) { atomicMin(p.result, (unsigned long long)cand); break; }
+    }
 }
 
 // ---- gathers for the query phase -----------------------------------------------------------------------------------------
