@@ -525,20 +525,19 @@ extern "C" int gl_pow_grind(gl_ctx* ctx, const uint64_t sponge_state[12], const 
     for (int i = 0; i < 12; i++) pw.state[i] = sponge_state[i];
     for (uint32_t i = 0; i < input_len; i++) pw.state[i] = input_buffer[i];
     pw.pos = input_len; pw.min_leading_zeros = min_leading_zeros; pw.result = d_res;
-    // expected 2^pow_bits candidates.  One launch covers a window of 16 * 2^pow_bits (it fails to contain a witness with
-    // probability e^-16) but hashes only up to the first witness plus one sweep (k_pow_grind); the window's atomicMin keeps
-    // the result the global minimum.  (A window is at most 2^34 candidates.)
-    const uint64_t batch = min_leading_zeros >= 30 ? (uint64_t(1) << 34) : (uint64_t(16) << min_leading_zeros);
-    // one sweep = half the expected number of candidates (32768 lanes at 16 bits), at most 2^22 lanes: harder puzzles fill the GPU
-    const uint64_t half = (uint64_t(1) << min_leading_zeros) / 2 / 256;
-    const uint64_t sweep_blocks = half < 1 ? 1 : (half > 16384 ? 16384 : half);
+    // (measured, 16 proofs in flight: windows of 2^pow_bits, and a small grid that walks a longer window in ascending sweeps and
+    // stops at the first witness -- 40 % fewer permutations -- gave the same 287 proofs/s within noise, resp. 8 % less for
+    // sweeps of 2^15 lanes whose long low-occupancy launches hold up their proof; the grind is 2.7 % of a proof's instructions)
+    // expected 2^pow_bits candidates: scan ascending windows of 2 * 2^pow_bits (86 % hit rate each) so that little work
+    // is wasted; the window's atomicMin keeps the result the global minimum
+    // (a window is at most 2^30 candidates: the grid dimension is 32 bits)
+    const uint64_t batch = min_leading_zeros >= 29 ? (uint64_t(1) << 30) : (uint64_t(2) << min_leading_zeros);
     unsigned long long res = ~0ull;
     ctx->timing_begin("find proof-of-work witness");
     for (uint64_t base = 0; base < GL_P; base += batch) {
         GL_CHECK_HIP(hipMemsetAsync(d_res, 0xFF, sizeof(unsigned long long), st));
         pw.base = base; pw.count = (GL_P - base < batch) ? GL_P - base : batch;
-        const uint64_t blocks = (pw.count + 255) / 256;
-        hipLaunchKernelGGL(k_pow_grind, dim3((unsigned)(blocks < sweep_blocks ? blocks : sweep_blocks)), dim3(256), 0, st, pw);
+        hipLaunchKernelGGL(k_pow_grind, dim3((unsigned)((pw.count + 255) / 256)), dim3(256), 0, st, pw);
         GL_CHECK_HIP(hipGetLastError());
         GL_TRY(d2h(ctx, &res, d_res, sizeof res));
         if (res != ~0ull) break;

@@ -576,26 +576,20 @@ __global__ __launch_bounds__(256) void k_fri_fold(const gl_t* ia, const gl_t* ib
 }
 
 // ---- proof of work: smallest w >= base with clz(permute(state with w at pos)[7]) >= bits ----------------------------------
-// A grid of about 2^bits / 2 lanes (gl_pow_grind) walks the window in ascending sweeps and every lane stops as soon as a
-// witness below its next candidate is known, so about 2^bits + one sweep candidates are hashed (a whole-window launch hashes the
-// full window: 2.3 x 2^bits for a window of 2 x 2^bits).  The minimum is exact: a lane only skips candidates above a witness
-// that has already been found.  Every lane leaves the loop after at most count / (gridDim.x * blockDim.x) + 1 iterations.
 struct GlPowParams { gl_t state[12]; uint32_t pos, min_leading_zeros; uint64_t base, count; unsigned long long* result; };
 __global__ __launch_bounds__(256) void k_pow_grind(GlPowParams p) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < p.count; idx += stride) {
-        const uint64_t cand = p.base + idx;
-        if (__hip_atomic_load(p.result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cand) break;
-        gl_t s[12];
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.count) return;
+    const uint64_t cand = p.base + idx;
+    gl_t s[12];
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = p.state[i];
+    for (int i = 0; i < 12; i++) s[i] = p.state[i];
 #pragma unroll
-        for (int i = 0; i < 8; i++) if ((uint32_t)i == p.pos) s[i] = cand;
-        psd_permute(s);
-        const gl_t r = gl_canon(s[7]);
-        const uint32_t lz = r ? (uint32_t)__clzll((long long)r) : 64u;
-        if (lz >= p.min_leading_zeros) { atomicMin(p.result, (unsigned long long)cand); break; }
-    }
+    for (int i = 0; i < 8; i++) if ((uint32_t)i == p.pos) s[i] = cand;
+    psd_permute(s);
+    const gl_t r = gl_canon(s[7]);
+    const uint32_t lz = r ? (uint32_t)__clzll((long long)r) : 64u;
+    if (lz >= p.min_leading_zeros) atomicMin(p.result, (unsigned long long)cand);
 }
 
 // ---- gathers for the query phase -----------------------------------------------------------------------------------------
