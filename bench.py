@@ -51,6 +51,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 LOG_N = 20
 M = 64
+VALU_CLOCK_HZ = 2.4e9          # MI355X peak engine clock (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 ALGO_BYTES_PER_PROOF_M64 = 2.0e9
 
@@ -521,6 +522,21 @@ def main():
                 "hbm": {"algorithmic_bytes_per_proof": ALGO_BYTES_PER_PROOF_M64 if m == 64 else None,
                         "achieved_GBs": per_gpu * ALGO_BYTES_PER_PROOF_M64 / 1e9 if m == 64 else None,
                         "frac_of_peak": per_gpu * ALGO_BYTES_PER_PROOF_M64 / 1e9 / HBM_PEAK_GBS if m == 64 else None}}
+            vp = os.path.join(ROOT, "profiles", "prove_m64_valu.json")
+            if m == 64 and os.path.exists(vp):
+                # the whole proof against the VALU issue roof: every kernel family of prove() is integer-ALU work, and a SIMD
+                # issues one wave-wide VALU instruction per 4 cycles (16 lanes), whatever the opcode (profiles/README.md)
+                try:
+                    per_proof = json.load(open(vp))["valu_wave_instructions_per_proof"]
+                    peak = 256 * 4 * VALU_CLOCK_HZ / 4.0
+                    out["roofline_prove"]["valu_issue"] = {
+                        "wave_instructions_per_proof": per_proof, "achieved_per_s": per_gpu * per_proof, "peak_per_s": peak,
+                        "frac": per_gpu * per_proof / peak,
+                        "peak_is": "256 CUs x 4 SIMDs x %.1f GHz / 4 cycles per wave64 instruction" % (VALU_CLOCK_HZ / 1e9),
+                        "source": "profiles/prove_m64_valu.json: SQ_INSTS_VALU of tools/prove_profile.py, difference of two proof counts "
+                                  "(committed profile, not measured in this run)"}
+                except Exception:
+                    pass
         if world == 1 and not args.no_extra:
             del lanes[1:]
             c4_dt, _, c4_ok = run_config4(args.batch, args.pool_lanes)
