@@ -334,6 +334,19 @@ def main():
             sys.stderr.write("bench.py: rank %d: CPU affinity %d -> %d cores after the RCCL init, restored\n" % (rank, len(affinity), len(after)))
             os.sched_setaffinity(0, affinity)
 
+    # every proof in flight has a host thread that drives its ~10 transcript round trips (and polls its stream): with N ranks on
+    # one host the lanes per rank are capped by the rank's share of the usable cores (never below 4)
+    try:
+        cores_per_rank = max(1, len(os.sched_getaffinity(0)) // max(1, world))
+    except AttributeError:
+        cores_per_rank = max(1, (os.cpu_count() or 1) // max(1, world))
+    for name in ("streams", "pool_lanes"):
+        want = getattr(args, name)
+        if want > max(4, cores_per_rank):
+            setattr(args, name, max(4, cores_per_rank))
+            if rank == 0:
+                sys.stderr.write("bench.py: --%s %d -> %d (%d usable cores per rank)\n" % (name.replace("_", "-"), want, getattr(args, name), cores_per_rank))
+
     import plonky2_demo_amd as p
     from plonky2_demo_amd import sharding
     from plonky2_demo_amd._lib import check, lib

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <thread>
 #include <map>
 #include <tuple>
 #include <mutex>
@@ -37,12 +38,15 @@ int gl_fail(int code, const char* what, const char* file, int line);
 // Wait for a stream by polling it.  hipStreamSynchronize follows the device's scheduling flags, and a process that has brought
 // up RCCL blocks on an interrupt there: every one of the ~10 transcript round trips of a proof then pays a wake-up latency
 // (measured: 245 -> 210 proofs/s with a one-rank process group).  Polling is independent of what other libraries set.
+// After ~2000 polls (tens of microseconds) the thread offers its core between polls: with more proofs in flight than cores
+// (8 ranks x 16 lanes on one host) a pure spin would keep the threads that have work to submit off the CPU.
 inline hipError_t gl_stream_wait(hipStream_t s) {
-    for (;;) {
+    for (unsigned spins = 0;; spins++) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
+        if (spins >= 2000) std::this_thread::yield();
 #if defined(__x86_64__)
-        __builtin_ia32_pause();
+        else __builtin_ia32_pause();
 #endif
     }
 }
