@@ -62,7 +62,7 @@ static int batch_from_host(gl_ctx* c, const uint64_t* const* h_cols, size_t ncol
         hipError_t e = hipMemcpyAsync(b->coeffs + col * n, h_cols[col], n * sizeof(gl_t), hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) { gl_batch_free(b); return gl_fail(GL_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__); }
     }
-    GL_CHECK_HIP(hipStreamSynchronize(c->stream));   // caller-owned pageable columns
+    GL_CHECK_HIP(gl_stream_wait(c->stream));   // caller-owned pageable columns
     int st = batch_commit(c, b, is_values ? b->coeffs : nullptr);
     if (st != GL_OK) { gl_batch_free(b); return st; }
     *out = b;

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
-#include <thread>
+#include <chrono>
+#include <time.h>
+#include <sys/prctl.h>
 #include <map>
 #include <tuple>
 #include <mutex>
@@ -38,16 +40,30 @@ int gl_fail(int code, const char* what, const char* file, int line);
 // Wait for a stream by polling it.  hipStreamSynchronize follows the device's scheduling flags, and a process that has brought
 // up RCCL blocks on an interrupt there: every one of the ~10 transcript round trips of a proof then pays a wake-up latency
 // (measured: 245 -> 210 proofs/s with a one-rank process group).  Polling is independent of what other libraries set.
-// After ~2000 polls (tens of microseconds) the thread offers its core between polls: with more proofs in flight than cores
-// (8 ranks x 16 lanes on one host) a pure spin would keep the threads that have work to submit off the CPU.
+// One or two waiting threads spin (a lone proof's latency is the sum of ~15 such waits, and a sleeping poll adds ~35 us to
+// each: 6.3 -> 6.8 ms measured).  With more waiters -- many proofs in flight -- a wait lasts milliseconds, and spinning threads
+// exhaust the CPU quota (measured on the 1-GPU box, 16 lanes: the cgroup throttled the process in half of its scheduling
+// periods, and 24 or 32 lanes ran 20-40 % SLOWER than 16) and keep threads that have work to submit off the cores when several
+// ranks share a host: after ~50 us those threads sleep ~20 us between polls.
+inline std::atomic<int> gl_stream_waiters{0};
 inline hipError_t gl_stream_wait(hipStream_t s) {
-    for (unsigned spins = 0;; spins++) {
-        const hipError_t e = hipStreamQuery(s);
+    hipError_t e = hipStreamQuery(s);
+    if (e != hipErrorNotReady) return e;
+    static thread_local bool slack_set = false;
+    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }     // 1 us instead of the default 50 us
+    struct Count { Count() { gl_stream_waiters.fetch_add(1, std::memory_order_relaxed); } ~Count() { gl_stream_waiters.fetch_sub(1, std::memory_order_relaxed); } } count;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
-        if (spins >= 2000) std::this_thread::yield();
+        if (gl_stream_waiters.load(std::memory_order_relaxed) <= 2 || std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(50)) {
 #if defined(__x86_64__)
-        else __builtin_ia32_pause();
+            __builtin_ia32_pause();
 #endif
+        } else {
+            struct timespec ts = {0, 20000};
+            (void)nanosleep(&ts, nullptr);
+        }
     }
 }
 

@@ -237,7 +237,7 @@ extern "C" int gl_merkle_new(gl_ctx* c, const uint64_t* h_leaves, size_t num_lea
     std::unique_ptr<gl_merkle, void (*)(gl_merkle*)> t(new gl_merkle(), gl_merkle_free);      // error paths free everything
     t->ctx = c; c->retain(); t->num_leaves = num_leaves; t->leaf_len = leaf_len;
     const size_t bytes = num_leaves * leaf_len * sizeof(gl_t);
-    struct Scratch { gl_ctx* c; gl_t* p = nullptr; ~Scratch() { if (p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); } } } cols{c};
+    struct Scratch { gl_ctx* c; gl_t* p = nullptr; ~Scratch() { if (p) { (void)gl_stream_wait(c->stream); (void)hipFree(p); } } } cols{c};
     GL_CHECK_HIP(hipMalloc((void**)&t->leaves, bytes));
     GL_CHECK_HIP(hipMalloc((void**)&cols.p, bytes));
     GL_TRY(gl_copy_h2d(c, t->leaves, h_leaves, bytes));
@@ -283,7 +283,7 @@ extern "C" int gl_merkle_prove(const gl_merkle* t, size_t leaf_index, uint64_t* 
 extern "C" void gl_merkle_free(gl_merkle* t) {
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
-    (void)hipStreamSynchronize(t->ctx->stream);
+    (void)gl_stream_wait(t->ctx->stream);
     gl_merkle_release(t->ctx, &t->tree);
     if (t->leaves) (void)hipFree(t->leaves);
     gl_ctx_release(t->ctx);

@@ -25,14 +25,14 @@ int gl_ctx::activate() {
 }
 int gl_ctx::ensure_scratch(size_t elems) {
     if (elems <= scratch_elems) return GL_OK;
-    if (scratch) { GL_CHECK_HIP(hipStreamSynchronize(stream)); GL_CHECK_HIP(hipFree(scratch)); scratch = nullptr; scratch_elems = 0; }
+    if (scratch) { GL_CHECK_HIP(gl_stream_wait(stream)); GL_CHECK_HIP(hipFree(scratch)); scratch = nullptr; scratch_elems = 0; }
     GL_CHECK_HIP(hipMalloc((void**)&scratch, elems * sizeof(gl_t)));
     scratch_elems = elems;
     return GL_OK;
 }
 int gl_ctx::ensure_pinned(size_t bytes) {
     if (bytes <= pinned_bytes) return GL_OK;
-    if (pinned) { GL_CHECK_HIP(hipStreamSynchronize(stream)); GL_CHECK_HIP(hipHostFree(pinned)); pinned = nullptr; pinned_bytes = 0; }
+    if (pinned) { GL_CHECK_HIP(gl_stream_wait(stream)); GL_CHECK_HIP(hipHostFree(pinned)); pinned = nullptr; pinned_bytes = 0; }
     size_t sz = bytes < (1u << 20) ? (1u << 20) : bytes;
     GL_CHECK_HIP(hipHostMalloc(&pinned, sz, hipHostMallocDefault));
     pinned_bytes = sz;
@@ -40,7 +40,7 @@ int gl_ctx::ensure_pinned(size_t bytes) {
 }
 int gl_ctx::ensure_dev_small(size_t bytes) {
     if (bytes <= dev_small_bytes) return GL_OK;
-    if (dev_small) { GL_CHECK_HIP(hipStreamSynchronize(stream)); GL_CHECK_HIP(hipFree(dev_small)); dev_small = nullptr; dev_small_bytes = 0; }
+    if (dev_small) { GL_CHECK_HIP(gl_stream_wait(stream)); GL_CHECK_HIP(hipFree(dev_small)); dev_small = nullptr; dev_small_bytes = 0; }
     size_t sz = bytes < (1u << 20) ? (1u << 20) : bytes;
     GL_CHECK_HIP(hipMalloc((void**)&dev_small, sz));
     dev_small_bytes = sz;
@@ -114,7 +114,7 @@ void gl_ctx::pool_release(void* p) {
 }
 void gl_ctx::pool_trim() {
     std::lock_guard<std::mutex> lk(pool_mu);
-    (void)hipStreamSynchronize(stream);
+    (void)gl_stream_wait(stream);
     for (auto& kv : pool_free_blocks) { pool_bytes -= kv.first; pool_block_size.erase(kv.second); (void)hipFree(kv.second); }
     pool_free_blocks.clear();
 }
@@ -146,7 +146,7 @@ extern "C" int gl_ctx_timing_enable(gl_ctx* c, int on) {
 extern "C" int gl_ctx_timing_reset(gl_ctx* c) {
     GL_REQUIRE(c, GL_ERR_ARG, "null ctx");
     GL_TRY(c->activate());
-    GL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    GL_CHECK_HIP(gl_stream_wait(c->stream));
     for (auto& r : c->timing_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     c->timing_recs.clear();
     c->timing_stack.clear();
@@ -156,7 +156,7 @@ extern "C" int gl_ctx_timing_reset(gl_ctx* c) {
 extern "C" int gl_ctx_timing_report(gl_ctx* c, char* buf, size_t cap) {
     GL_REQUIRE(c && buf && cap > 2, GL_ERR_ARG, "bad argument");
     GL_TRY(c->activate());
-    GL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    GL_CHECK_HIP(gl_stream_wait(c->stream));
     std::map<std::string, std::pair<uint64_t, double>> agg;
     std::vector<std::string> order;
     for (auto& r : c->timing_recs) {
@@ -186,7 +186,7 @@ int gl_ctx::get_offsets_table(const uint64_t* host, size_t len, const uint64_t**
     uint64_t* d = nullptr;
     GL_CHECK_HIP(hipMalloc((void**)&d, len * sizeof(uint64_t)));
     GL_CHECK_HIP(hipMemcpyAsync(d, host, len * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-    GL_CHECK_HIP(hipStreamSynchronize(stream));   // first use only
+    GL_CHECK_HIP(gl_stream_wait(stream));   // first use only
     offset_tables[key] = d;
     *d_out = d;
     return GL_OK;
@@ -218,7 +218,7 @@ extern "C" int gl_ctx_create(int device, void* stream, gl_ctx** out) {
 // the last reference is gone: nothing points at the context any more
 static void gl_ctx_teardown(gl_ctx* c) {
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)gl_stream_wait(c->stream);
     for (auto& r : c->timing_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     for (int d = 0; d < 2; d++) if (c->tw_local[d]) (void)hipFree(c->tw_local[d]);
     c->pool_trim();
@@ -241,7 +241,7 @@ void gl_ctx_release(gl_ctx* c) {
 extern "C" void gl_ctx_destroy(gl_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)gl_stream_wait(c->stream);
     gl_ctx_release(c);
 }
 extern "C" int gl_ctx_synchronize(gl_ctx* c) {
@@ -264,7 +264,7 @@ extern "C" int gl_dev_alloc(gl_ctx* c, size_t bytes, void** d_out) {
 }
 extern "C" int gl_dev_free(gl_ctx* c, void* d_ptr) {
     // plain device memory: a null context (already destroyed by the caller) is accepted, the whole device is drained instead
-    if (c) { GL_TRY(c->activate()); GL_CHECK_HIP(hipStreamSynchronize(c->stream)); }
+    if (c) { GL_TRY(c->activate()); GL_CHECK_HIP(gl_stream_wait(c->stream)); }
     else GL_CHECK_HIP(hipDeviceSynchronize());
     GL_CHECK_HIP(hipFree(d_ptr));
     return GL_OK;
@@ -273,12 +273,23 @@ extern "C" int gl_copy_h2d(gl_ctx* c, void* d_dst, const void* h_src, size_t byt
     GL_REQUIRE(c && d_dst && h_src, GL_ERR_ARG, "null argument");
     GL_TRY(c->activate());
     GL_CHECK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
-    GL_CHECK_HIP(hipStreamSynchronize(c->stream));   // pageable source must not be reused before the copy lands
+    GL_CHECK_HIP(gl_stream_wait(c->stream));   // pageable source must not be reused before the copy lands
     return GL_OK;
 }
 extern "C" int gl_copy_d2h(gl_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
     GL_REQUIRE(c && h_dst && d_src, GL_ERR_ARG, "null argument");
     GL_TRY(c->activate());
+    // A copy to pageable memory makes the runtime wait for the stream INSIDE hipMemcpyAsync, spinning (measured: each of 16
+    // proofs in flight kept a core at 100 % there).  Small results go through the context's pinned buffer -- the copy is then
+    // really asynchronous and the wait sleeps between polls; large ones wait for the stream first.
+    if (bytes <= (size_t(4) << 20)) {
+        GL_TRY(c->ensure_pinned(bytes));
+        GL_CHECK_HIP(hipMemcpyAsync(c->pinned, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        GL_CHECK_HIP(gl_stream_wait(c->stream));
+        memcpy(h_dst, c->pinned, bytes);
+        return GL_OK;
+    }
+    GL_CHECK_HIP(gl_stream_wait(c->stream));
     GL_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     GL_CHECK_HIP(gl_stream_wait(c->stream));
     return GL_OK;

@@ -159,7 +159,7 @@ static int circuit_finish(gl_ctx* ctx, const gl_circuit_desc* desc, const gl_t* 
         GL_TRY(gl_copy_h2d(ctx, ctx->dev_small, zh, sizeof zh));
         hipLaunchKernelGGL(k_l0_on_coset, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, xt.lo, xt.hi, (uint32_t)N, (gl_t)n, ctx->dev_small, c->d_l0_coset);
         GL_CHECK_HIP(hipGetLastError());
-        GL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        GL_CHECK_HIP(gl_stream_wait(ctx->stream));
     }
     // circuit_digest = hash_no_pad(cap || hash_pad([]) || [degree_bits])   (circuit_builder.rs:1089-1100)
     std::vector<gl_t> parts((size_t(4) << desc->cap_height));
@@ -346,7 +346,7 @@ extern "C" int gl_quotient_polys(gl_ctx* ctx, const gl_circuit* cir, const gl_ba
     std::vector<gl_t> apow;
     GL_TRY(quotient_chunks(ctx, cir, wires, zs_partial_products, pi_hash, betas, gammas, alphas, d_q.as<gl_t>(), apow));
     int rc = gl_batch_from_device(ctx, d_q.as<uint64_t>(), 16, cir->n, cir->desc.rate_bits, cir->desc.cap_height, 0, out);
-    GL_CHECK_HIP(hipStreamSynchronize(ctx->stream));      // `apow` was the source of an async upload
+    GL_CHECK_HIP(gl_stream_wait(ctx->stream));      // `apow` was the source of an async upload
     return rc;
 }
 
@@ -391,7 +391,7 @@ struct gl_fri {
 extern "C" void gl_fri_free(gl_fri* f) {
     if (!f) return;
     gl_ctx* ctx = f->ctx;
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx) (void)gl_stream_wait(ctx->stream);
     delete f;                                  // its trees and buffers go back to the context's pool first
     gl_ctx_release(ctx);
 }

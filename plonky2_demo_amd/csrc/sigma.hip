@@ -67,6 +67,6 @@ int gl_sigmas_from_classes(gl_ctx* c, const uint64_t* d_classes, uint32_t lgn, u
     hipLaunchKernelGGL(k_sigma_values, dim3(blocks), dim3(256), 0, st, (const uint64_t*)key_out.p, (const uint32_t*)val_out.p, (const uint32_t*)val_in.p, total, n,
                        (const gl_t*)kis.p, xt.lo, xt.hi, d_sigma);
     GL_CHECK_HIP(hipGetLastError());
-    GL_CHECK_HIP(hipStreamSynchronize(st));          // `k` (host source of the async upload) dies here
+    GL_CHECK_HIP(gl_stream_wait(st));          // `k` (host source of the async upload) dies here
     return GL_OK;
 }

@@ -60,7 +60,7 @@ extern "C" void gl_matmul_witgen_free(gl_matmul_witgen* g) {
     if (!g) return;
     if (g->ctx) {
         (void)g->ctx->activate();
-        (void)hipStreamSynchronize(g->ctx->stream);
+        (void)gl_stream_wait(g->ctx->stream);
         if (g->d_mul_row) g->ctx->pool_release(g->d_mul_row);
         if (g->d_add_row) g->ctx->pool_release(g->d_add_row);
         if (g->d_ab) g->ctx->pool_release(g->d_ab);
@@ -145,7 +145,7 @@ extern "C" int gl_matmul_witgen_run(gl_matmul_witgen* g, const uint64_t* a, cons
     GL_CHECK_HIP(hipMemcpy2DAsync((gl_t*)d_wires + h.first_poseidon_row, n * sizeof(gl_t), sp, R * sizeof(gl_t), R * sizeof(gl_t), 135,
                                   hipMemcpyHostToDevice, st));
     ctx->timing_end();
-    GL_CHECK_HIP(hipStreamSynchronize(st));                // the pinned staging buffers are reused by the next call
+    GL_CHECK_HIP(gl_stream_wait(st));                // the pinned staging buffers are reused by the next call
     return GL_OK;
 }
 
