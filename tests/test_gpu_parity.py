@@ -563,6 +563,21 @@ def test_demo_binary_builds_proves_and_verifies(gpu):
     assert r.returncode == 0 and "all accepted" in r.stderr, r.stderr
 
 
+def test_hand_scheduled_primitives_against_int128(gpu):
+    # tools/ubench/wide_acc.hip: the quotient's unreduced alpha-weighted sums (GlxWideAcc2), the 7 y = 8 y - y step and the
+    # canonical factor chains of the permutation argument, each against unsigned __int128 arithmetic on the host
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "ubench", "bin", "wide_acc")
+    src = os.path.join(root, "tools", "ubench", "wide_acc.hip")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "plonky2_demo_amd", "csrc"), src, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FAIL" not in r.stdout and r.stdout.count(": ok") == 3, r.stdout
+
+
 def test_concurrent_proofs_on_shared_circuit_are_deterministic(gpu):
     # four contexts (streams) of one device prove against ONE device-resident circuit from four host threads, as bench.py
     # does: every proof must equal the single-stream proof of the same witness byte for byte (no cross-stream state)

@@ -29,9 +29,11 @@ __global__ void k_factors(const gl_t* wv_, const gl_t* sg_, const gl_t* bxk_, gl
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const gl_t wv = wv_[i], sg = sg_[i], bxk = bxk_[i];
+    // numerator factor w + (beta k x) + gamma, denominator factor w + beta sigma + gamma (vanishing_poly.rs:279-300)
     const gl_t f = glx_add_cc(glx_add_cc(wv, bxk), gamma);
-    const gl_t wb = glx_canon(gl_mul(wv, beta));
-    const gl_t g = glx_add_cc(glx_add_cc(wb, sg), gamma);
+    gl_t sb, u1, u2;
+    glx_mul3<true>(sg, beta, 0, 0, 0, 0, sb, u1, u2);
+    const gl_t g = glx_add_cc(glx_add_cc(wv, sb), gamma);
     const gl_t f_ref = gl_canon(gl_add(gl_add(wv, bxk), gamma));
     const gl_t g_ref = gl_canon(gl_add(gl_mul_add(wv, beta, sg), gamma));
     o[4 * i] = f; o[4 * i + 1] = g; o[4 * i + 2] = f_ref; o[4 * i + 3] = g_ref;
@@ -86,7 +88,7 @@ int main() {
         (void)hipMemcpy(of.data(), dof, n * 32, hipMemcpyDeviceToHost);
         int badf = 0;
         for (size_t i = 0; i < n; i++) {
-            const uint64_t fr = h_mod((unsigned __int128)wv[i] + bx[i] + gamma), gr = h_mod((unsigned __int128)h_mod((unsigned __int128)wv[i] * beta) + sg[i] + gamma);
+            const uint64_t fr = h_mod((unsigned __int128)wv[i] + bx[i] + gamma), gr = h_mod((unsigned __int128)h_mod((unsigned __int128)sg[i] * beta) + wv[i] + gamma);
             if (of[4 * i] != fr || of[4 * i + 1] != gr || of[4 * i + 2] != fr || of[4 * i + 3] != gr) { if (badf < 5) printf("  factors MISMATCH i=%zu f=%016llx f_ref=%016llx want=%016llx | g=%016llx g_ref=%016llx want=%016llx\n", i, (unsigned long long)of[4 * i], (unsigned long long)of[4 * i + 2], (unsigned long long)fr, (unsigned long long)of[4 * i + 1], (unsigned long long)of[4 * i + 3], (unsigned long long)gr); badf++; }
         }
         printf("factor chains: %s (%d mismatches)\n", badf ? "FAIL" : "ok", badf);
