@@ -215,6 +215,14 @@ __device__ __forceinline__ gl_t glx_mul(gl_t a, gl_t b) {
     return glx_mk64(y0, y1);
 }
 
+// x * c + k for a compile-time c in [0, 64] and a wave-uniform 64-bit k: the first term of a multiply-add chain that starts
+// from a constant.  The constant rides in as the scalar addend (c is an inline constant, so the instruction's one scalar
+// operand is free for it); written in C the compiler first copies k into a vector register pair (two moves per chain).
+__device__ __forceinline__ gl_t glx_mad_k(uint32_t x, uint32_t c /* a constant after inlining and unrolling */, uint64_t k) {
+    gl_t r;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(x), "i"(c), "s"(k) : "vcc");
+    return r;
+}
 // lo + top * EPS (mod p) with one fix-up, valid while lo + top * EPS < 2^65 - 2^32 (goldilocks_field.rs:346-351 reduce96):
 // v_mad_u64_u32 does the multiply by EPS, the 64-bit add and the carry in one instruction
 __device__ __forceinline__ gl_t glx_reduce96(gl_t lo, uint32_t top) {
@@ -450,6 +458,7 @@ __device__ void glx_mul3(gl_t aA, gl_t bA, gl_t aB, gl_t bB, gl_t aC, gl_t bC, g
 template <bool CANON>
 __device__ gl_t glx_mul(gl_t a, gl_t b);
 __device__ gl_t glx_reduce96(gl_t lo, uint32_t top);
+__device__ gl_t glx_mad_k(uint32_t x, uint32_t c, uint64_t k);
 __device__ gl_t glx_canon(gl_t x);
 __device__ gl_t glx_add_eps_if(gl_t z, uint32_t bit);
 __device__ gl_t glx_add_cc(gl_t a, gl_t b);

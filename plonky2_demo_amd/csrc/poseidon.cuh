@@ -169,10 +169,11 @@ GL_HD void psd_mds_then_constants(gl_t (&s)[12], const gl_t* __restrict__ rc) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int r = r0 + k;
-            al[k] = 0; ah[k] = 0;          // each < (256 + 8 + 1) * 2^32 < 2^41
-            if (WITH_RC) { const gl_t c = rc[r]; al[k] = (uint32_t)c; ah[k] = c >> 32; }
+            // each < (256 + 8 + 1) * 2^32 < 2^41; the round constant is the scalar addend of the first multiply-add (glx_mad_k)
+            if (WITH_RC) { const gl_t c = rc[r]; al[k] = glx_mad_k(lo[r], 17u, (uint64_t)(uint32_t)c); ah[k] = glx_mad_k(hi[r], 17u, c >> 32); }
+            else { al[k] = (gl_t)lo[r] * 17u; ah[k] = (gl_t)hi[r] * 17u; }
 #pragma unroll
-            for (int i = 0; i < 12; i++) {
+            for (int i = 1; i < 12; i++) {
                 al[k] += (gl_t)lo[(i + r) % 12] * circ[i];
                 ah[k] += (gl_t)hi[(i + r) % 12] * circ[i];
             }
@@ -243,19 +244,17 @@ __device__ __forceinline__ void psd_partial_group(gl_t (&s)[12], int g, const gl
     a[0] = s[0];
     const gl_t d0 = gl_sub(psd_sbox(SUBST ? in[0] : s[0]), s[0]);
     const uint32_t d0l = (uint32_t)d0, d0h = (uint32_t)(d0 >> 32);
-    gl_t al = (uint32_t)K[0], ah = K[0] >> 32;
+    gl_t al = glx_mad_k(d0l, 25u, (uint64_t)(uint32_t)K[0]), ah = glx_mad_k(d0h, 25u, K[0] >> 32);      // M[0][0]
 #pragma unroll
     for (int i = 0; i < 12; i++) { const uint32_t c = psd_mds_entry(0, i); al += (gl_t)lo[i] * c; ah += (gl_t)hi[i] * c; }
-    al += (gl_t)d0l * 25u; ah += (gl_t)d0h * 25u;                      // M[0][0]
     const gl_t a1 = psd_acc_reduce(al, ah);
     a[1] = a1;
     const gl_t d1 = gl_sub(psd_sbox(SUBST ? in[1] : a1), a1);
     const uint32_t d1l = (uint32_t)d1, d1h = (uint32_t)(d1 >> 32);
-    al = (uint32_t)K[1]; ah = K[1] >> 32;
+    al = glx_mad_k(d1l, 25u, (uint64_t)(uint32_t)K[1]); ah = glx_mad_k(d1h, 25u, K[1] >> 32);      // (inline-constant coefficient first)
 #pragma unroll
     for (int i = 0; i < 12; i++) { const uint32_t c = R2[i]; al += (gl_t)lo[i] * c; ah += (gl_t)hi[i] * c; }
     { const uint32_t c = V1[0]; al += (gl_t)d0l * c; ah += (gl_t)d0h * c; }
-    al += (gl_t)d1l * 25u; ah += (gl_t)d1h * 25u;
     const gl_t a2 = psd_acc_reduce(al, ah);
     a[2] = a2;
     const gl_t d2 = gl_sub(psd_sbox(SUBST ? in[2] : a2), a2);
@@ -266,12 +265,14 @@ __device__ __forceinline__ void psd_partial_group(gl_t (&s)[12], int g, const gl
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int l = l0 + k;
-            xl[k] = (uint32_t)K[2 + l]; xh[k] = K[2 + l] >> 32;
+            // the term with a compile-time (inline-constant) coefficient goes first: its multiply-add takes the round constant as
+            // a scalar 64-bit addend, which a multiply-add with a scalar coefficient cannot (one scalar operand per instruction)
+            // -- otherwise every accumulator starts with two register moves
+            xl[k] = glx_mad_k(d2l, psd_mds_entry(l, 0), (uint64_t)(uint32_t)K[2 + l]); xh[k] = glx_mad_k(d2h, psd_mds_entry(l, 0), K[2 + l] >> 32);
 #pragma unroll
             for (int i = 0; i < 12; i++) { const uint32_t c = M3[12 * l + i]; xl[k] += (gl_t)lo[i] * c; xh[k] += (gl_t)hi[i] * c; }
             { const uint32_t c = V2[l]; xl[k] += (gl_t)d0l * c; xh[k] += (gl_t)d0h * c; }
             { const uint32_t c = V1[l]; xl[k] += (gl_t)d1l * c; xh[k] += (gl_t)d1h * c; }
-            { const uint32_t c = psd_mds_entry(l, 0); xl[k] += (gl_t)d2l * c; xh[k] += (gl_t)d2h * c; }
         }
         glx_acc_reduce3(xl[0], xh[0], xl[1], xh[1], xl[2], xh[2], s[l0], s[l0 + 1], s[l0 + 2]);
     }
