@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 # mode) independent proofs in flight on as many streams; once RCCL adds its own streams two proofs share a queue and serialise
 # (measured: 246 -> 212 proofs/s with a one-rank process group, 246 again with 8 queues; profiles/README.md).  Must be set
 # before the HIP runtime initialises, i.e. before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")      # 16 proofs in flight + RCCL's own streams (16 queues: 270 proofs/s under RCCL, 20-24: 287)
 
 LOG_N = 20
 M = 64
