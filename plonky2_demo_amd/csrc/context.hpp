@@ -99,9 +99,13 @@ struct gl_ctx {
     gl_t* scratch = nullptr;
     size_t scratch_elems = 0;
     size_t scratch_target = size_t(1) << 24;                      // 128 MiB: stays Infinity-Cache resident
-    // small pinned staging for D2H of caps / openings / query rows
-    void* pinned = nullptr;
-    size_t pinned_bytes = 0;
+    // pinned staging buffers for small device-to-host results (caps, openings, query rows).  A context's stream may be used by
+    // several host threads at once (proofs on other contexts read the shared circuit's batches through ITS context), so a
+    // buffer is taken from this list for one copy and handed back afterwards
+    std::mutex pin_mu;
+    std::vector<std::pair<void*, size_t>> pin_free;
+    int pin_acquire(size_t bytes, void** out, size_t* cap);
+    void pin_release(void* p, size_t cap);
     gl_t* dev_small = nullptr;                                    // 1 MiB device staging
     size_t dev_small_bytes = 0;
 
@@ -131,7 +135,6 @@ struct gl_ctx {
 
     int activate();
     int ensure_scratch(size_t elems);
-    int ensure_pinned(size_t bytes);
     int ensure_dev_small(size_t bytes);
     int get_pow_table(gl_t base, gl_t scale, uint32_t hi_len, GlPowTable* out);
     std::vector<gl_t*> retired_tables;      // superseded (shorter) power tables: possibly still in flight, freed with the context

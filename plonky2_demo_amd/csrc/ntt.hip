@@ -30,13 +30,20 @@ int gl_ctx::ensure_scratch(size_t elems) {
     scratch_elems = elems;
     return GL_OK;
 }
-int gl_ctx::ensure_pinned(size_t bytes) {
-    if (bytes <= pinned_bytes) return GL_OK;
-    if (pinned) { GL_CHECK_HIP(gl_stream_wait(stream)); GL_CHECK_HIP(hipHostFree(pinned)); pinned = nullptr; pinned_bytes = 0; }
-    size_t sz = bytes < (1u << 20) ? (1u << 20) : bytes;
-    GL_CHECK_HIP(hipHostMalloc(&pinned, sz, hipHostMallocDefault));
-    pinned_bytes = sz;
+int gl_ctx::pin_acquire(size_t bytes, void** out, size_t* cap) {
+    {
+        std::lock_guard<std::mutex> lk(pin_mu);
+        for (size_t i = 0; i < pin_free.size(); i++)
+            if (pin_free[i].second >= bytes) { *out = pin_free[i].first; *cap = pin_free[i].second; pin_free.erase(pin_free.begin() + i); return GL_OK; }
+    }
+    const size_t sz = bytes < (size_t(1) << 20) ? (size_t(1) << 20) : bytes;
+    GL_CHECK_HIP(hipHostMalloc(out, sz, hipHostMallocDefault));
+    *cap = sz;
     return GL_OK;
+}
+void gl_ctx::pin_release(void* p, size_t cap) {
+    std::lock_guard<std::mutex> lk(pin_mu);
+    pin_free.emplace_back(p, cap);
 }
 int gl_ctx::ensure_dev_small(size_t bytes) {
     if (bytes <= dev_small_bytes) return GL_OK;
@@ -228,7 +235,7 @@ static void gl_ctx_teardown(gl_ctx* c) {
     for (auto& kv : c->pass_tables) (void)hipFree(kv.second);
     for (auto& kv : c->offset_tables) (void)hipFree(kv.second);
     if (c->scratch) (void)hipFree(c->scratch);
-    if (c->pinned) (void)hipHostFree(c->pinned);
+    for (auto& pb : c->pin_free) (void)hipHostFree(pb.first);
     if (c->dev_small) (void)hipFree(c->dev_small);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -280,13 +287,16 @@ extern "C" int gl_copy_d2h(gl_ctx* c, void* h_dst, const void* d_src, size_t byt
     GL_REQUIRE(c && h_dst && d_src, GL_ERR_ARG, "null argument");
     GL_TRY(c->activate());
     // A copy to pageable memory makes the runtime wait for the stream INSIDE hipMemcpyAsync, spinning (measured: each of 16
-    // proofs in flight kept a core at 100 % there).  Small results go through the context's pinned buffer -- the copy is then
+    // proofs in flight kept a core at 100 % there).  Small results go through one of the context's pinned buffers -- the copy is then
     // really asynchronous and the wait sleeps between polls; large ones wait for the stream first.
     if (bytes <= (size_t(4) << 20)) {
-        GL_TRY(c->ensure_pinned(bytes));
-        GL_CHECK_HIP(hipMemcpyAsync(c->pinned, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
-        GL_CHECK_HIP(gl_stream_wait(c->stream));
-        memcpy(h_dst, c->pinned, bytes);
+        void* stage = nullptr; size_t cap = 0;
+        GL_TRY(c->pin_acquire(bytes, &stage, &cap));
+        hipError_t e = hipMemcpyAsync(stage, d_src, bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = gl_stream_wait(c->stream);
+        if (e == hipSuccess) memcpy(h_dst, stage, bytes);
+        c->pin_release(stage, cap);
+        GL_CHECK_HIP(e);
         return GL_OK;
     }
     GL_CHECK_HIP(gl_stream_wait(c->stream));
