@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+# the concurrency tests keep 16 proofs in flight: give them as many hardware queues as bench.py does (HIP's default of 4 would
+# serialise them four to a queue); read by the HIP runtime when it initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 
 def pytest_configure(config):

@@ -612,6 +612,48 @@ def test_concurrent_proofs_on_shared_circuit_are_deterministic(gpu):
         assert by == wits[k][2], (lane, rep, k)
 
 
+def test_sixteen_proofs_in_flight_m64_soak(gpu):
+    # bench.py's configuration: 16 contexts, the first of them the circuit's own, 16 host threads, m = 64 -- and, as tools/soak.py
+    # does, every thread now and then verifies a proof, which reads the circuit's Merkle cap through the CIRCUIT's context while
+    # that context is proving on another thread (round 2: a single pinned staging buffer per context corrupted one proof in
+    # 40-250 this way, while the 4-lane m = 20 test above stayed green).  Every proof must equal the single-stream proof of
+    # its witness.
+    import hashlib, threading
+    p, ctx = gpu
+    m, nl, per_lane = 64, 16, 24
+    hc = p.MatmulCircuit(m)
+    cd = hc.build(ctx)
+    wits = []
+    for k in range(5):
+        a, b = rand_field(700 + k, m * m) % (2**32 - 1), rand_field(800 + k, m * m) % (2**32 - 1)
+        wires, pis = hc.witness(a, b, filler_seed=k)
+        buf = ctx.alloc(wires.nbytes).upload(wires)
+        ref = cd.prove_device(buf.ptr, pis).to_bytes()
+        assert cd.verify(ref) == (True, "")
+        wits.append((buf, pis, hashlib.sha256(ref).digest()))
+    lanes = [(ctx, cd)] + [(lambda c: (c, p.api.CircuitView(cd, c)))(p.Context(device=0)) for _ in range(nl - 1)]
+    bad, errors = [], []
+
+    def work(lane):
+        try:
+            for rep in range(per_lane):
+                k = (lane + rep) % len(wits)
+                by = lanes[lane][1].prove_device(wits[k][0].ptr, wits[k][1]).to_bytes()
+                if hashlib.sha256(by).digest() != wits[k][2]:
+                    bad.append((lane, rep, k))
+                elif (lane + rep) % 5 == 0 and cd.verify(by) != (True, ""):    # reads the circuit's cap through the circuit's context
+                    bad.append((lane, rep, k, "rejected"))
+            lanes[lane][0].synchronize()
+        except Exception as e:
+            errors.append((lane, e))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(nl)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors
+    assert not bad, bad
+
+
 def test_phase_api_rejects_mismatched_arguments(gpu):
     # the reference asserts on shape errors (oracle.rs:114,169); the phase entry points return GL_ERR_ARG instead
     p, ctx = gpu
