@@ -20,7 +20,11 @@
  *    text for the calling thread.  The reference panics on shape errors (oracle.rs:114,
  *    merkle_tree.rs:137-143, fft.rs:175-181); here they are GL_ERR_ARG.
  *  - A gl_ctx is bound to one device and one HIP stream; calls on one ctx are issued in order on that
- *    stream.  Different ctxs may be used concurrently from different threads.
+ *    stream.  Different ctxs may be used concurrently from different threads; ONE ctx runs one computing call at a
+ *    time.  The plain copies out of a handle -- gl_batch_cap / gl_batch_coeffs / gl_batch_lde, gl_merkle_cap,
+ *    gl_circuit_digest / gl_circuit_constants_sigmas_cap -- go through the context the handle was created on and MAY be
+ *    called from any thread while that context is computing on another (a verifier thread reads the cap of a circuit that
+ *    is proving); the getters that gather on the device first (get_leaf, prove, get_lde_values) count as computing calls.
  *  - Lifetime: every handle created on a context (gl_batch, gl_merkle, gl_circuit, gl_fri, gl_matmul_witgen) holds a
  *    reference to it.  gl_ctx_destroy() drops the creator's reference: after it the gl_ctx pointer must not be passed to
  *    any entry point again, but handles created earlier stay valid (they keep the stream, tables and allocator alive)
