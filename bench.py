@@ -90,7 +90,43 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(m):
+def cpu_micro_rows(orc, oracle_lib, threads):
+    """BASELINE.md section 3's CPU columns for the micro-kernel rows, on bounded samples (opt-in: --cpu-rows)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    L = 1 << 20
+
+    def med3(fn):
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return sorted(ts)[1]
+    x1 = oracle_lib.rand_field(70, (1, L))
+    t_fft1 = med3(lambda: orc.fft(x1))
+    xb = [oracle_lib.rand_field(71 + i, (1, L)) for i in range(threads)]
+    with ThreadPoolExecutor(threads) as ex:                       # ctypes releases the GIL: one transform per core
+        t_fftn = med3(lambda: list(ex.map(orc.fft, xb)))
+    c1 = oracle_lib.rand_field(80, (2, 1 << 17))
+    t_lde1 = med3(lambda: orc.lde(c1, 3, threads=1)) / 2 * 135
+    cn = oracle_lib.rand_field(81, (max(2, min(threads, 135)), 1 << 17))
+    t_lden = med3(lambda: orc.lde(cn, 3, threads=threads)) / cn.shape[0] * 135
+    leaves = oracle_lib.rand_field(82, (1 << 14, 135))                                   # 1/16 of the 2^18 leaves
+    t0 = time.perf_counter(); orc.merkle(leaves, 4); t_mk1 = (time.perf_counter() - t0) * 16
+    perms = (1 << 18) * 17 + (1 << 18) - 16
+    return {
+        "ntt_2^20": {"one_thread_GF_elems_per_s": L / t_fft1, "all_cores_GF_elems_per_s": threads * L / t_fftn,
+                     "one_thread_GBs": 16.0 * L / t_fft1 / 1e9, "all_cores_GBs": 16.0 * L * threads / t_fftn / 1e9,
+                     "sample": "1 / %d polynomials of 2^20, median of 3" % threads},
+        "coset_lde_2^17_to_2^20_x135": {"one_thread_s": t_lde1, "all_cores_s": t_lden, "one_thread_GBs": 72.0 * (1 << 17) * 135 / t_lde1 / 1e9,
+                                        "all_cores_GBs": 72.0 * (1 << 17) * 135 / t_lden / 1e9,
+                                        "sample": "2 columns (1 thread) / %d columns (%d threads), scaled to 135" % (cn.shape[0], threads)},
+        "merkle_commit_2^18_x135_cap4": {"one_thread_s": t_mk1, "one_thread_permutations_per_s": perms / t_mk1,
+                                         "sample": "2^14 of the 2^18 leaves on 1 thread, scaled x16"},
+        "threads": threads,
+    }
+
+
+def cpu_baseline(m, rows=False):
     """BASELINE ONLY: times the oracle's prove() (C++ restatement of plonk/prover.rs) on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -120,8 +156,9 @@ def cpu_baseline(m):
     t0 = time.perf_counter(); orc.batch(vals, 3, 4, from_values=True, threads=1); t1 = time.perf_counter() - t0
     t0 = time.perf_counter(); orc.batch(vals, 3, 4, from_values=True, threads=threads); tn = time.perf_counter() - t0
     speedup = t1 / tn
+    micro = cpu_micro_rows(orc, oracle_lib, threads) if rows else None
     return {
-        "value": 1.0 / med, "unit": "proofs/s", "cores": cores, "threads": threads, "kind": "port",
+        "value": 1.0 / med, "unit": "proofs/s", "cores": cores, "threads": threads, "kind": "port", "micro_kernel_rows": micro,
         "runs_s": [round(t, 3) for t in times],
         "one_thread": {"value": 1.0 / (med * speedup), "unit": "proofs/s", "derived": True,
                        "sample_commit_1_thread_s": round(t1, 3), "sample_commit_all_threads_s": round(tn, 3), "parallel_speedup": round(speedup, 2)},
@@ -285,6 +322,7 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--cpu-rows", action="store_true", help="cpu_baseline also times the CPU columns of BASELINE.md section 3's micro-kernel rows (adds ~20 s)")
     ap.add_argument("--steps", type=int, default=320)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--m", type=int, default=M)
@@ -556,7 +594,7 @@ def main():
             out["config4_batch512"] = {"value": args.batch / c4_dt, "unit": "proofs/s", "proofs": args.batch, "seconds": round(c4_dt, 3), "n_gpus": 1,
                                        "proofs_in_flight": args.pool_lanes, "first_proof_verifies": bool(c4_ok),
                                        "includes": "operands from host memory, witness generation in HBM, prove(); the multi-GPU form is `bench.py --gpus N --config4`"}
-        out["cpu_baseline"] = cpu_baseline(m) if (world == 1 and not args.no_cpu) else None
+        out["cpu_baseline"] = cpu_baseline(m, rows=args.cpu_rows) if (world == 1 and not args.no_cpu) else None
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
