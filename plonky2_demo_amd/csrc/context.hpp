@@ -50,7 +50,6 @@ inline hipError_t gl_stream_wait(hipStream_t s) {
     hipError_t e = hipStreamQuery(s);
     if (e != hipErrorNotReady) return e;
     static thread_local bool slack_set = false;
-    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }     // 1 us instead of the default 50 us
     struct Count { Count() { gl_stream_waiters.fetch_add(1, std::memory_order_relaxed); } ~Count() { gl_stream_waiters.fetch_sub(1, std::memory_order_relaxed); } } count;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -61,6 +60,8 @@ inline hipError_t gl_stream_wait(hipStream_t s) {
             __builtin_ia32_pause();
 #endif
         } else {
+            // (the first sleeping wait of a thread lowers ITS timer slack from the default 50 us to 1 us; nothing else is changed)
+            if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }
             struct timespec ts = {0, 20000};
             (void)nanosleep(&ts, nullptr);
         }
