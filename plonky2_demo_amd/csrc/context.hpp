@@ -46,6 +46,9 @@ int gl_fail(int code, const char* what, const char* file, int line);
 // periods, and 24 or 32 lanes ran 20-40 % SLOWER than 16) and keep threads that have work to submit off the cores when several
 // ranks share a host: after ~50 us those threads sleep ~20 us between polls.
 inline std::atomic<int> gl_stream_waiters{0};
+// proofs currently inside gl_prove* in this process (any context): with several in flight the GPU's issue slots are the bound
+// and latency-hiding variants that spend more instructions per result stop paying (merkle.hip gl_coop_max_nodes)
+inline std::atomic<int> gl_proofs_in_flight{0};
 inline hipError_t gl_stream_wait(hipStream_t s) {
     hipError_t e = hipStreamQuery(s);
     if (e != hipErrorNotReady) return e;

@@ -19,10 +19,15 @@ struct gl_merkle {
 };
 
 #define GL_COOP_MAX_NODES_DEFAULT 8192u      // 8192 hashes x 16 lanes = 2048 waves = 2 per SIMD
+#define GL_COOP_MAX_NODES_THROUGHPUT 1024u   // with more than two proofs in flight
 // tuning knob (environment GL_COOP_MAX_NODES): launches of at most this many hashes use the 16-lane cooperative permutation
 static uint32_t gl_coop_max_nodes() {
-    static const uint32_t v = [] { const char* e = getenv("GL_COOP_MAX_NODES"); return e ? (uint32_t)strtoul(e, nullptr, 10) : GL_COOP_MAX_NODES_DEFAULT; }();
-    return v;
+    static const long env = [] { const char* e = getenv("GL_COOP_MAX_NODES"); return e ? (long)strtoul(e, nullptr, 10) : -1L; }();
+    if (env >= 0) return (uint32_t)env;
+    // The 16-lane hash costs 3.5 x the instructions of the lane-per-hash one and buys latency.  With several proofs in flight
+    // the other proofs hide that latency and the issue slots are what is scarce: measured with 16 in flight, thresholds of
+    // 2048 / 512 / 128 give 287 proofs/s against 281-283 for 8192.  (The tree tops, <= 64 nodes per cap subtree, stay fused.)
+    return gl_proofs_in_flight.load(std::memory_order_relaxed) > 2 ? GL_COOP_MAX_NODES_THROUGHPUT : GL_COOP_MAX_NODES_DEFAULT;
 }
 
 __device__ __forceinline__ uint32_t d_bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
@@ -165,9 +170,10 @@ int gl_merkle_build(gl_ctx* c, const gl_t* base, const uint64_t* host_offsets, u
     const uint64_t* d_off = nullptr;
     GL_TRY(c->get_offsets_table(host_offsets, leaf_len, &d_off));
     const uint32_t n = 1u << lg_leaves;
+    const uint32_t coop = gl_coop_max_nodes();                 // one decision per tree
     c->timing_begin("merkle_leaf_hash");
-    // below gl_coop_max_nodes() one-lane-per-hash launches cannot fill the 1024 SIMDs: use 16 lanes per hash (latency / 3)
-    if (n <= gl_coop_max_nodes()) hipLaunchKernelGGL(k_merkle_leaves_coop, dim3((n * 16 + 255) / 256), dim3(256), 0, c->stream, base, d_off, leaf_len, lg_leaves, out->level_ptr(0));
+    // below the threshold one-lane-per-hash launches cannot fill the 1024 SIMDs: use 16 lanes per hash (latency / 3)
+    if (n <= coop) hipLaunchKernelGGL(k_merkle_leaves_coop, dim3((n * 16 + 255) / 256), dim3(256), 0, c->stream, base, d_off, leaf_len, lg_leaves, out->level_ptr(0));
     else {
         static const int wpe = [] { const char* e = getenv("GL_LEAF_WPE"); return e ? atoi(e) : 5; }();      // tuning knob
         auto kern = wpe >= 8 ? k_merkle_leaves<8> : wpe == 7 ? k_merkle_leaves<7> : wpe == 6 ? k_merkle_leaves<6> : wpe == 4 ? k_merkle_leaves<4> : k_merkle_leaves<5>;
@@ -178,7 +184,7 @@ int gl_merkle_build(gl_ctx* c, const gl_t* base, const uint64_t* host_offsets, u
     c->timing_begin("merkle_levels");
     // levels with at most GL_TOP_NODES nodes per cap subtree are finished by one launch (k_merkle_top_coop)
     uint32_t top_first = levels;
-    if (gl_coop_max_nodes() > 0)
+    if (coop > 0)
         for (uint32_t l = 1; l < levels; l++)
             if (((1u << (lg_leaves - l)) >> cap_height) <= GL_TOP_NODES && ((1u << (lg_leaves - l)) >> cap_height) >= 1) { top_first = l; break; }
     const uint64_t* d_lev_off = nullptr;
@@ -186,7 +192,7 @@ int gl_merkle_build(gl_ctx* c, const gl_t* base, const uint64_t* host_offsets, u
     else top_first = levels;
     for (uint32_t l = 1; l < top_first; l++) {
         const uint32_t cnt = 1u << (lg_leaves - l);
-        if (cnt <= gl_coop_max_nodes()) hipLaunchKernelGGL(k_merkle_level_coop, dim3((cnt * 16 + 255) / 256), dim3(256), 0, c->stream, out->level_ptr(l - 1), out->level_ptr(l), cnt);
+        if (cnt <= coop) hipLaunchKernelGGL(k_merkle_level_coop, dim3((cnt * 16 + 255) / 256), dim3(256), 0, c->stream, out->level_ptr(l - 1), out->level_ptr(l), cnt);
         else hipLaunchKernelGGL(k_merkle_level, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, out->level_ptr(l - 1), out->level_ptr(l), cnt);
     }
     if (top_first < levels)

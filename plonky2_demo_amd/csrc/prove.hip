@@ -678,6 +678,7 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     const gl_circuit_desc& d = cir->desc;
     GL_REQUIRE(npis == d.num_public_inputs, GL_ERR_ARG, "gl_prove: wrong number of public inputs");
     GL_TRY(ctx->activate());
+    struct InFlight { InFlight() { gl_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); } ~InFlight() { gl_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); } } in_flight;
     const size_t n = cir->n, N = n << d.rate_bits;
     const uint32_t lgn = d.degree_bits, ncap = 4u << d.cap_height;
     hipStream_t st = ctx->stream;
