@@ -27,11 +27,16 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ
 cp $(find $OUT/sq_ntt -name "*counter_collection.csv" | head -1) $OUT/${R}_ntt20_pmc_sq_counters.csv
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/sq_prove -o s --output-format csv -- python3 $ROOT/tools/prove_profile.py 64 2 > $OUT/${R}_prove_m64_scopes.txt 2>&1
 cp $(find $OUT/sq_prove -name "*counter_collection.csv" | head -1) $OUT/${R}_prove_m64_pmc_sq_counters.csv
+# the per-proof instruction count of the THROUGHPUT configuration (what bench.py's 16 proofs in flight run): the profile proves one
+# at a time, so the two choices the library makes from the number of proofs in flight are pinned through their knobs
+export GL_COOP_MAX_NODES=1024 GL_POW_WINDOW_LOG=0
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU -d $OUT/sq_prove2t -o s --output-format csv -- python3 $ROOT/tools/prove_profile.py 64 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU -d $OUT/sq_prove8 -o s --output-format csv -- python3 $ROOT/tools/prove_profile.py 64 8 > /dev/null 2>&1
-python3 $ROOT/tools/valu_report.py $OUT/${R}_prove_m64_pmc_sq_counters.csv $(find $OUT/sq_prove8 -name "*counter_collection.csv" | head -1) $OUT/prove_m64_valu.json > /dev/null
+python3 $ROOT/tools/valu_report.py $(find $OUT/sq_prove2t -name "*counter_collection.csv" | head -1) $(find $OUT/sq_prove8 -name "*counter_collection.csv" | head -1) $OUT/prove_m64_valu.json > /dev/null
+unset GL_COOP_MAX_NODES GL_POW_WINDOW_LOG
 echo "[6] NTT ablation (memory-only time of the passes)"
 cd $ROOT && bash tools/ablation.sh > $OUT/${R}_ntt_ablation.txt 2>&1
 echo "[7] m = 128 (config 5)"
 python3 $ROOT/tools/prove_profile.py 128 3 > $OUT/${R}_prove_m128_scopes.txt 2>&1
-rm -rf $OUT/kt_prove $OUT/kt_ntt $OUT/pmc_fetch $OUT/pmc_write $OUT/sq_ntt $OUT/sq_prove $OUT/sq_prove8
+rm -rf $OUT/kt_prove $OUT/kt_ntt $OUT/pmc_fetch $OUT/pmc_write $OUT/sq_ntt $OUT/sq_prove $OUT/sq_prove2t $OUT/sq_prove8
 ls -la $OUT

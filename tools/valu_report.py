@@ -25,6 +25,6 @@ out = {"proofs_in_difference": proofs, "valu_wave_instructions_per_proof": total
        "share": {k: round(v / total, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1]) if v / total >= 0.002},
        "launches_per_proof": {k: round((lb[k] - la.get(k, 0)) / proofs, 2) for k in per if (lb[k] - la.get(k, 0))},
        "hash_kernels_share": round(poseidon / total, 4),
-       "source": "rocprofv3 --pmc SQ_INSTS_VALU ... of tools/prove_profile.py 64 2 and 64 8 (tools/collect_profiles.sh), difference of the two runs"}
+       "source": "rocprofv3 --pmc SQ_INSTS_VALU ... of tools/prove_profile.py 64 2 and 64 8 (tools/collect_profiles.sh), difference of the two runs, with the choices the library makes for several proofs in flight pinned (GL_COOP_MAX_NODES=1024 GL_POW_WINDOW_LOG=0)"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
