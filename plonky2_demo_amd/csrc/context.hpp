@@ -102,7 +102,10 @@ struct gl_ctx {
     int get_pass_table(gl_t w, gl_t scale, uint32_t lgN1, uint32_t lgN2, const gl_t** out);
     gl_t* scratch = nullptr;
     size_t scratch_elems = 0;
-    size_t scratch_target = size_t(1) << 24;                      // 128 MiB: stays Infinity-Cache resident
+    // inter-pass scratch: at most 2^26 elements (512 MiB), i.e. 64 polynomials of 2^20 per column/row launch pair.  Fewer, larger
+    // launches beat keeping the scratch Infinity-Cache resident: forward 2^20 x 64 takes 0.829 / 0.751 / 0.737 / 0.722 ms with
+    // 2^23 / 2^24 / 2^25 / 2^26 elements (8 / 4 / 2 / 1 launch pairs); prove() is indifferent (+0.6 %)
+    size_t scratch_target = size_t(1) << 26;
     // pinned staging buffers for small device-to-host results (caps, openings, query rows).  A context's stream may be used by
     // several host threads at once (proofs on other contexts read the shared circuit's batches through ITS context), so a
     // buffer is taken from this list for one copy and handed back afterwards

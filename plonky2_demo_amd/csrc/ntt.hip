@@ -209,6 +209,7 @@ extern "C" int gl_ctx_create(int device, void* stream, gl_ctx** out) {
     std::unique_ptr<gl_ctx, void (*)(gl_ctx*)> holder(new gl_ctx(), gl_ctx_release);      // nothing leaks on an error path
     gl_ctx* c = holder.get();
     c->device = device;
+    if (const char* e = getenv("GL_NTT_SCRATCH_LOG")) { const int lg = atoi(e); if (lg >= 16 && lg <= 32) c->scratch_target = size_t(1) << lg; }      // tuning knob
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { GL_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     const uint32_t len = 1u << NTT_LOCAL_MAX_LOG;

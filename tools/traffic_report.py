@@ -4,6 +4,7 @@ Counter units are KiB per dispatch (MI355X_MICROARCH.md, HBM section); the read 
 dispatches (known 8n bytes read with the same 8-byte-per-lane access shape) instead of assuming the x2 rule."""
 import csv, glob, json, os, sys
 root, B = sys.argv[1], int(sys.argv[2])
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3          # forward NTTs prof_traffic.py ran (its second argument)
 def load(pattern, counter):
     rows = []
     for f in glob.glob(os.path.join(root, pattern, "**", "*counter_collection.csv"), recursive=True):
@@ -30,8 +31,8 @@ for key in ("ntt_col_pass", "ntt_row_pass"):
     per[key] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_read_bytes": f * 1024 * corr_f, "hbm_write_bytes": w * 1024 * corr_w, "dispatches_seen": cnt}
     launches[key] = cnt
 out["per_launch"] = per
-# one forward NTT over B polynomials = (B*2^20*8 / scratch) chunks x (col + row)
-chunks = max(1, (B << 20) // (1 << 24))
+# one forward NTT over B polynomials = (B * 2^20 / inter-pass scratch elements) chunks x (col + row): counted from the dispatches seen
+chunks = max(1, round(launches["ntt_col_pass"] / reps))
 out["launches_per_forward_ntt"] = {"ntt_col_pass": chunks, "ntt_row_pass": chunks}
 out["forward_ntt_hbm_bytes"] = chunks * sum(per[k]["hbm_read_bytes"] + per[k]["hbm_write_bytes"] for k in per)
 out["algorithmic_bytes"] = 16.0 * n
