@@ -178,7 +178,7 @@ def timed_launches(ctx, fn, reps):
     return rep
 
 
-def ntt_leg(torch, ctx, lib, check, dev, batch):
+def ntt_leg(torch, ctx, lib, check, dev, batch, with_rows=True):
     L = 1 << LOG_N
     data = synth_field(torch, (batch, L), 20, dev)
     ref = data.clone()
@@ -243,6 +243,9 @@ def ntt_leg(torch, ctx, lib, check, dev, batch):
     ntt["poseidon"] = {"permutations_per_s": perm_per_s, "modular_multiplies_per_s": perm_per_s * 472,
                        "note": "one 12-word state per lane (k_poseidon_states, 2^23 states): the integer-ALU rate that bounds prove()"}
     del dst, states, ref
+    if not with_rows:
+        del data
+        return roofline, ntt, None, perm_per_s
     # the other micro-kernel rows
     extra = {}
     for b2 in (1, 16, 256):
@@ -336,7 +339,7 @@ def main():
     ap.add_argument("--pool-lanes", type=int, default=16, help="proofs in flight per GPU in the config-4 batch")
     ap.add_argument("--spawn", action="store_true", help="run even a 1-GPU job as a spawned rank over RCCL (the N > 1 code path)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the micro-kernel rows (NTT batches, LDE, Merkle commit)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other micro-kernel rows (NTT at batch 1/16/256, LDE, Merkle commit) and the config-4 batch")
     args = ap.parse_args()
 
     if "RANK" not in os.environ and (args.gpus > 1 or args.spawn):
@@ -541,7 +544,8 @@ def main():
                    "proofs_in_flight": nl,
                    "includes": "witness generation from host operands (GPU arithmetic rows + host hash-sponge rows) + prove()"}
             del gens, bufs, el
-        roofline, ntt, extra, perm_ceiling = ntt_leg(torch, ctx, lib, check, dev, args.ntt_batch) if not args.no_extra else (None, None, None, None)
+        # the roofline kernel (forward 2^20 NTT x 64) and the Poseidon ceiling always run; --no-extra skips the other micro-kernel rows
+        roofline, ntt, extra, perm_ceiling = ntt_leg(torch, ctx, lib, check, dev, args.ntt_batch, with_rows=not args.no_extra)
         ctx.timing(True)
         step(0)
         scopes = {k: round(v["ms"], 4) for k, v in ctx.timing_report().items()}

@@ -13,7 +13,7 @@ echo "[2] kernel stats of the prove() loop"
 rocprofv3 --kernel-trace --stats -d $OUT/kt_prove -o kt --output-format csv -- python3 $ROOT/bench.py --steps 320 --no-cpu --no-extra --e2e-steps 0 > /dev/null 2>&1
 cp $OUT/kt_prove/kt_kernel_stats.csv $OUT/${R}_bench_prove_m64_kernel_stats.csv
 python3 $ROOT/tools/busy.py $OUT/kt_prove/kt_kernel_trace.csv 0.5 > $OUT/${R}_bench_prove_m64_gpu_busy.txt
-echo "[3] kernel stats of the 2^20 NTT x 64"
+echo "[3] kernel stats of the 2^20 NTT x 64 ([2] holds them too: bench.py --no-extra keeps the roofline leg, 2^20 x 64 launches only)"
 rocprofv3 --kernel-trace --stats -d $OUT/kt_ntt -o kt --output-format csv -- python3 $ROOT/tools/prof_ntt.py 64 40 > /dev/null 2>&1
 cp $OUT/kt_ntt/kt_kernel_stats.csv $OUT/${R}_ntt20_kernel_stats.csv
 echo "[4] HBM traffic of the forward NTT (separate FETCH_SIZE / WRITE_SIZE passes)"
