@@ -570,7 +570,8 @@ def test_hand_scheduled_primitives_against_int128(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "tools", "ubench", "bin", "wide_acc")
     src = os.path.join(root, "tools", "ubench", "wide_acc.hip")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    hdr = os.path.join(root, "plonky2_demo_amd", "csrc", "gl64_gfx950.cuh")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         os.makedirs(os.path.dirname(exe), exist_ok=True)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "plonky2_demo_amd", "csrc"), src, "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
