@@ -126,7 +126,7 @@ def cpu_micro_rows(orc, oracle_lib, threads):
     }
 
 
-def cpu_baseline(m, rows=False):
+def cpu_baseline(m, rows=False, one_thread_full=False):
     """BASELINE ONLY: times the oracle's prove() (C++ restatement of plonk/prover.rs) on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -159,14 +159,19 @@ def cpu_baseline(m, rows=False):
     t0 = time.perf_counter(); orc.batch(vals, 3, 4, from_values=True, threads=threads); tn = time.perf_counter() - t0
     speedup = t1 / tn
     micro = cpu_micro_rows(orc, oracle_lib, threads) if rows else None
+    measured_1t = None
+    if one_thread_full:                             # opt-in (--cpu-one-thread): one full proof on ONE thread, about a minute
+        t0 = time.perf_counter(); p1 = w.prove(threads=1); t_full1 = time.perf_counter() - t0
+        measured_1t = {"value": 1.0 / t_full1, "unit": "proofs/s", "seconds": round(t_full1, 2), "verifies": bool(p1.verify()[0])}
     return {
-        "value": 1.0 / med, "unit": "proofs/s", "cores": cores, "threads": threads, "kind": "port", "micro_kernel_rows": micro,
+        "value": 1.0 / med, "unit": "proofs/s", "cores": cores, "threads": threads, "kind": "port", "micro_kernel_rows": micro, "one_thread_measured": measured_1t,
         "runs_s": [round(t, 3) for t in times],
         "one_thread": {"value": 1.0 / (med * speedup), "unit": "proofs/s", "derived": True,
                        "sample_commit_1_thread_s": round(t1, 3), "sample_commit_all_threads_s": round(tn, 3), "parallel_speedup": round(speedup, 2)},
         "sample": "all cores: median of %d full proofs (after one warm-up proof) of the m=%d circuit by the C++ restatement of the reference prover (oracle/gl_prover.hpp), "
                   "%d threads on %d usable cores over the reference's Rayon axes, verifier restatement %s; 1 thread: the all-core figure "
-                  "divided by the parallel speed-up measured on the proof's 20-column x 2^%d commitment (from_values, rate 3, cap 4)"
+                  "divided by the parallel speed-up measured on the proof's 20-column x 2^%d commitment (from_values, rate 3, cap 4) -- a lower "
+                  "bound: a full 1-thread proof measured with --cpu-one-thread takes 45 s on the GPU box's host (profiles/r02_cpu_one_thread.json)"
                   % (len(times), m, threads, cores, "accepts" if ok else "REJECTS", oc.info["degree_bits"]),
     }
 
@@ -327,6 +332,7 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--cpu-one-thread", action="store_true", help="cpu_baseline also times one full proof on one thread (about a minute)")
     ap.add_argument("--cpu-rows", action="store_true", help="cpu_baseline also times the CPU columns of BASELINE.md section 3's micro-kernel rows (adds ~20 s)")
     ap.add_argument("--steps", type=int, default=320)
     ap.add_argument("--warmup", type=int, default=32)
@@ -600,7 +606,7 @@ def main():
             out["config4_batch512"] = {"value": args.batch / c4_dt, "unit": "proofs/s", "proofs": args.batch, "seconds": round(c4_dt, 3), "n_gpus": 1,
                                        "proofs_in_flight": args.pool_lanes, "first_proof_verifies": bool(c4_ok),
                                        "includes": "operands from host memory, witness generation in HBM, prove(); the multi-GPU form is `bench.py --gpus N --config4`"}
-        out["cpu_baseline"] = cpu_baseline(m, rows=args.cpu_rows) if (world == 1 and not args.no_cpu) else None
+        out["cpu_baseline"] = cpu_baseline(m, rows=args.cpu_rows, one_thread_full=args.cpu_one_thread) if (world == 1 and not args.no_cpu) else None
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
