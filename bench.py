@@ -9,11 +9,13 @@
           torch.distributed.run child, BEFORE anything in the parent touches the GPU -- waits, and relays rank 0's JSON line.
           Fewer than N visible devices is an error (exit 3), never a silent n_gpus = 1.
 
-A "step" is one pass of the hot path over one unit of synthetic input resident in HBM: one prove()
-(plonky2/src/plonk/prover.rs:102-329 from the full witness matrix on: 3 PolynomialBatch commitments, permutation argument,
-quotient, openings, FRI) of the m = 64 circuit (n = 2^15 rows, 135 wire columns, 250 756-byte proof).  Default mode
-(BASELINE configs[2], "scaling": "weak"): every rank proves K proofs of its own random witnesses, 16 in flight on 16 streams,
-witness matrices already in HBM when the clock starts; value = world * K / t.  Proofs are independent: circuit data is
+A "step" is one pass of the hot path over one batch of synthetic input resident in HBM: the 16 independent proofs a GPU keeps
+in flight, each one prove() (plonky2/src/plonk/prover.rs:102-329 from the full witness matrix on: 3 PolynomialBatch commitments,
+permutation argument, quotient, openings, FRI) of the m = 64 circuit (n = 2^15 rows, 135 wire columns, 250 756-byte proof).
+Default mode (BASELINE configs[2], "scaling": "weak"): every rank proves K steps = 16 K proofs of its own random witnesses, 16 in
+flight on 16 streams (the lanes run continuously, not batch by batch), witness matrices already in HBM when the clock starts;
+value = world * 16 K / t proofs/s, ms_per_step = t / K.  (With a step of ONE proof the driver's `--steps 20` would time 20 proofs
+on 16 lanes: a 70 ms region that never reaches the steady state.)  Proofs are independent: circuit data is
 replicated, there is no data-path collective; the only collective is one RCCL all_gather of the Merkle caps of the proved batch
 inside the timed region.
 
@@ -334,8 +336,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--cpu-one-thread", action="store_true", help="cpu_baseline also times one full proof on one thread (about a minute)")
     ap.add_argument("--cpu-rows", action="store_true", help="cpu_baseline also times the CPU columns of BASELINE.md section 3's micro-kernel rows (adds ~20 s)")
-    ap.add_argument("--steps", type=int, default=320)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; a step is one batch of --streams (16) proofs per GPU")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up steps (at least one)")
     ap.add_argument("--m", type=int, default=M)
     ap.add_argument("--witnesses", type=int, default=4, help="distinct random witnesses cycled through")
     ap.add_argument("--ntt-batch", type=int, default=64)
@@ -493,32 +495,36 @@ def main():
         for th in ths:
             th.join()
 
-    run_steps(0, max(args.warmup, nstreams), [None] * max(args.warmup, nstreams))
+    # a step = one batch of `nstreams` proofs (what a GPU keeps in flight); the lanes run continuously, not batch by batch
+    per_step = nstreams
+    nproofs = args.steps * per_step
+    nwarm = max(1, args.warmup) * per_step
+    run_steps(0, nwarm, [None] * nwarm)
     if use_dist:                                            # untimed: brings the RCCL communicator up
         sharding.gather_caps(np.zeros((1, 3, 16, 4), dtype=np.uint64), world, device=dev)
         if os.environ.get("BENCH_RCCL_DIAG") == "destroy" and world == 1:      # diagnosis only (profiles/README.md)
             dist.destroy_process_group()
             use_dist = False
     barrier()
-    caps = [None] * args.steps
+    caps = [None] * nproofs
     t0 = time.perf_counter()
-    run_steps(0, args.steps, caps)
+    run_steps(0, nproofs, caps)
     gathered = None
     if use_dist:                                            # the Merkle-cap gather: 3 x 16 x 32 B per proof
         # rank r proved global proofs r, r + world, ... (round-robin); every rank ends with all caps in proof order
-        gathered = sharding.gather_caps(np.stack(caps), world * args.steps, device=dev)
+        gathered = sharding.gather_caps(np.stack(caps), world * nproofs, device=dev)
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        assert gathered.shape == (world * args.steps, 3, 16, 4)
+        assert gathered.shape == (world * nproofs, 3, 16, 4)
         assert (gathered[rank::world] == np.stack(caps)).all()
 
     proof_bytes = len(step(0).to_bytes())
     if rank == 0:
-        value = world * args.steps / dt
+        value = world * nproofs / dt
         # secondary figure (not `value`): the same loop with witness generation inside the clock -- operands on the host,
         # arithmetic rows filled by the GPU, the sequential public-input hash sponge by the lane's host thread
         e2e = None
@@ -567,6 +573,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "scaling": "weak",
             "config": {"workload": "prove_matmul_m%d" % m, "trace_rows": hc.n, "lde_size": hc.n << 3, "proof_bytes": proof_bytes,
+                       "step": "one batch of %d independent proofs per GPU" % per_step, "proofs_per_step_per_gpu": per_step,
+                       "proofs_timed": world * nproofs, "ms_per_proof": dt / (world * nproofs) * 1e3,
                        "witnesses_per_gpu": len(wit), "proofs_in_flight_per_gpu": nstreams, "parallelism": "independent proofs per GPU; RCCL all_gather of Merkle caps only"},
             "roofline": roofline,
             "ntt": ntt,

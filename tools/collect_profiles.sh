@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 echo "[1] bench.py (default flags)"
 python3 $ROOT/bench.py > $OUT/${R}_bench.json 2> $OUT/${R}_bench.err
 echo "[2] kernel stats of the prove() loop"
-rocprofv3 --kernel-trace --stats -d $OUT/kt_prove -o kt --output-format csv -- python3 $ROOT/bench.py --steps 320 --no-cpu --no-extra --e2e-steps 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt_prove -o kt --output-format csv -- python3 $ROOT/bench.py --steps 20 --no-cpu --no-extra --e2e-steps 0 > /dev/null 2>&1
 cp $OUT/kt_prove/kt_kernel_stats.csv $OUT/${R}_bench_prove_m64_kernel_stats.csv
 python3 $ROOT/tools/busy.py $OUT/kt_prove/kt_kernel_trace.csv 0.5 > $OUT/${R}_bench_prove_m64_gpu_busy.txt
 echo "[3] kernel stats of the 2^20 NTT x 64 ([2] holds them too: bench.py --no-extra keeps the roofline leg, 2^20 x 64 launches only)"

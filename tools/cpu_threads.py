@@ -3,7 +3,7 @@
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tck = os.sysconf("SC_CLK_TCK")
-proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-extra", "--e2e-steps", "0", "--steps", "960"] + sys.argv[1:],
+proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-extra", "--e2e-steps", "0", "--steps", "60"] + sys.argv[1:],
                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
 seen, running, samples = {}, {}, 0
 while proc.poll() is None:
