@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
-"""GPU busy fraction from a rocprofv3 --kernel-trace CSV: union of the kernel intervals over the span of the trace, and the
+"""GPU busy fraction from a rocprofv3 --kernel-trace CSV: union of the kernel intervals over the window of the prove() loop, and the
 time by kernel name.  python tools/busy.py <kernel_trace.csv> [skip_first_fraction]"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
-t0 = iv[0][0] + (iv[-1][1] - iv[0][0]) * skip       # drop the set-up phase
-iv = [x for x in iv if x[0] >= t0]
+# the window of the prove() loop: from the k_quotient launch `skip` of the way through (warm-up and set-up dropped) to the last
+# one -- the trace of bench.py also holds the NTT / Poseidon legs, which run alone with host gaps between their launches
+q = [x[0] for x in iv if x[2].startswith("void k_quotient<false>") or x[2].startswith("k_quotient<false>")]
+if len(q) >= 8:
+    lo, hi = q[int(len(q) * skip)], q[-1 - max(3, len(q) // 50)]      # (the last few proofs are bench.py's single scoped ones, after the other legs)
+    iv = [x for x in iv if lo <= x[0] <= hi]
+else:
+    t0 = iv[0][0] + (iv[-1][1] - iv[0][0]) * skip       # no proofs in the trace: drop the set-up phase
+    iv = [x for x in iv if x[0] >= t0]
 span = iv[-1][1] - iv[0][0]
 busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
 for s, e, _ in iv[1:]:
