@@ -85,6 +85,16 @@ def permutations_per_proof(n, rate_bits=3, cap_height=4, arity_bits=4, pow_bits=
     return total + N + (1 << pow_bits)
 
 
+def cpu_quota_cores():
+    """CPU time the cgroup grants per period, in cores (cgroup v2 cpu.max), or None: the affinity mask of a container often shows
+    every core of the host while the quota is a fraction of them."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
 def host_cores():
     try:
         return len(os.sched_getaffinity(0))       # the CPU share this process may actually run on
@@ -166,7 +176,7 @@ def cpu_baseline(m, rows=False, one_thread_full=False):
         t0 = time.perf_counter(); p1 = w.prove(threads=1); t_full1 = time.perf_counter() - t0
         measured_1t = {"value": 1.0 / t_full1, "unit": "proofs/s", "seconds": round(t_full1, 2), "verifies": bool(p1.verify()[0])}
     return {
-        "value": 1.0 / med, "unit": "proofs/s", "cores": cores, "threads": threads, "kind": "port", "micro_kernel_rows": micro, "one_thread_measured": measured_1t,
+        "value": 1.0 / med, "unit": "proofs/s", "cores": cores, "threads": threads, "cpu_quota_cores": cpu_quota_cores(), "kind": "port", "micro_kernel_rows": micro, "one_thread_measured": measured_1t,
         "runs_s": [round(t, 3) for t in times],
         "one_thread": {"value": 1.0 / (med * speedup), "unit": "proofs/s", "derived": True,
                        "sample_commit_1_thread_s": round(t1, 3), "sample_commit_all_threads_s": round(tn, 3), "parallel_speedup": round(speedup, 2)},
