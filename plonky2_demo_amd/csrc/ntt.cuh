@@ -22,12 +22,16 @@
 #include "gl64.cuh"
 #include "gl64_gfx950.cuh"
 
+#ifndef NTT_TILE_LOG
 #define NTT_TILE_LOG 13                 // elements per workgroup tile (8192 * 8 B = 64 KiB of LDS)
+#endif
 #ifndef NTT_THREADS
 #define NTT_THREADS 512                 // 512: 16 elements per thread, radix-16 register blocks, 4 waves per SIMD (2 workgroups per CU);
 #endif                                  // 1024: 8 per thread, radix-8 blocks, 8 waves per SIMD when the kernel fits 64 VGPRs
 #define NTT_EPT ((1 << NTT_TILE_LOG) / NTT_THREADS)   // elements per thread
+#ifndef NTT_WAVES_PER_SIMD
 #define NTT_WAVES_PER_SIMD (NTT_THREADS / 64 / 4 * 2)  // two workgroups per CU (LDS)
+#endif
 #define NTT_LOCAL_MAX_LOG 12            // largest in-LDS transform
 #ifdef NTT_ABLATION
 #define NTT_DBG(p, bit) ((p).debug & (bit))
@@ -56,6 +60,7 @@ struct NttPassParams {
 };
 
 __host__ __device__ constexpr int ntt_first_radix(int rem) {
+    if (NTT_EPT >= 32) return rem <= 5 ? rem : (rem == 6) ? 3 : (rem == 7 || rem == 8) ? 4 : 5;     // radix at most 32: 10 = 5 + 5
     if (NTT_EPT >= 16) return rem <= 4 ? rem : (rem == 5 || rem == 6 || rem == 9) ? 3 : 4;
     return rem <= 3 ? rem : (rem == 4 ? 2 : 3);          // radix at most 8: 10 = 3 + 3 + 2 + 2
 }
@@ -109,7 +114,8 @@ __device__ __forceinline__ void ntt_small_dft_l(gl_t* u) {
         if constexpr (H >= 4) {
             ntt_layer_diffs4<LOGR, INV, LG, 0>(u, d);
             if constexpr (H >= 8) ntt_layer_diffs4<LOGR, INV, LG, 4>(u, d);
-            static_assert(H <= 8, "radix at most 16");
+            if constexpr (H >= 16) { ntt_layer_diffs4<LOGR, INV, LG, 8>(u, d); ntt_layer_diffs4<LOGR, INV, LG, 12>(u, d); }
+            static_assert(H <= 16, "radix at most 32");
         } else {
 #pragma unroll
             for (int k = 0; k < H; k++) {
@@ -158,11 +164,24 @@ struct NttGeom {
     static constexpr bool WAVE_OWNED = ((1 << LOGL) <= 64 * NTT_EPT);          // a wave (64 lanes x NTT_EPT elements) holds whole columns
     static constexpr int LW = L + (L >> 4) + (T >= 32 ? 1 : 32 / T);           // column stride (elements), see at()
     static constexpr int LDT = T + 1;                                          // row stride of the legacy layout
-    static constexpr size_t LDS_BYTES = WAVE_OWNED ? (size_t)T * LW * 8 : (size_t)L * LDT * 8;
+#ifdef NTT_LDS_ALIAS    // DIAGNOSTIC ONLY (wrong results): the tile aliased onto 32 KiB, to time a higher occupancy before building it
+    static constexpr size_t LDS_BYTES = 32768 + (WAVE_OWNED ? (1 << LOGL) * 8 : 0);
+    static constexpr int TW_OFF = 4096;
+    __device__ static __forceinline__ int at(int t, int i) {
+        if constexpr (WAVE_OWNED) return (t * LW + i + (i >> 4)) & 4095;
+        else return (i * LDT + t) & 4095;
+    }
+#else
+    // wave-owned tiles also keep the stage twiddles w_L^e (e < L, 8 L bytes) behind the tile: 70 + 8 KiB for L = 1024, two
+    // workgroups per CU still fit the 160 KiB.  Loaded from global memory the 7 or 15 twiddles of a task were the largest
+    // single stall of a pass (round 3: 0.713 -> 0.634 ms for the 2^20 x 64 transform with the loads taken out).
+    static constexpr int TW_OFF = WAVE_OWNED ? T * LW : 0;                     // element offset of the table
+    static constexpr size_t LDS_BYTES = WAVE_OWNED ? ((size_t)T * LW + L) * 8 : (size_t)L * LDT * 8;
     __device__ static __forceinline__ int at(int t, int i) {
         if constexpr (WAVE_OWNED) return t * LW + i + (i >> 4);
         else return i * LDT + t;
     }
+#endif
 };
 
 __device__ __forceinline__ void ntt_wave_sync() {
@@ -239,7 +258,15 @@ __device__ __forceinline__ void ntt_lds_stages(gl_t* lds, const gl_t* __restrict
             if constexpr (LOGNS > 0) {
                 gl_t tw[R - 1];
 #pragma unroll
-                for (int r = 1; r < R; r++) tw[r - 1] = tw_local[(r * k) << (NTT_LOCAL_MAX_LOG - LOGNS - LOGR)];
+#ifdef NTT_NO_TW_LOADS      // DIAGNOSTIC ONLY (wrong results): what the stage twiddle loads from global memory cost
+                for (int r = 1; r < R; r++) tw[r - 1] = (gl_t)(r * k + 1) * 0x9E3779B97F4A7C15ULL >> 1;
+#else
+                for (int r = 1; r < R; r++) {
+                    // wave-owned tiles: from the table in LDS (filled by ntt_fill_lds_twiddles before the first barrier)
+                    if constexpr (G::WAVE_OWNED) tw[r - 1] = lds[G::TW_OFF + ((r * k) << (LOGL - LOGNS - LOGR))];
+                    else tw[r - 1] = tw_local[(r * k) << (NTT_LOCAL_MAX_LOG - LOGNS - LOGR)];
+                }
+#endif
                 ntt_mul_many<R - 1>(&u[q][1], tw);
             }
             ntt_small_dft<LOGR, INV>(u[q]);
@@ -249,6 +276,16 @@ __device__ __forceinline__ void ntt_lds_stages(gl_t* lds, const gl_t* __restrict
         }
         if constexpr (G::WAVE_OWNED) ntt_wave_sync(); else __syncthreads();
         ntt_lds_stages<LOGL, LOGNS + LOGR, INV, ZP>(lds, tw_local, tid);
+    }
+}
+
+// w_L^e, e < L, into the LDS table behind a wave-owned tile (visible after the workgroup barrier that follows the tile load)
+template <int LOGL>
+__device__ __forceinline__ void ntt_fill_lds_twiddles(gl_t* lds, const gl_t* __restrict__ tw_local, int tid) {
+    using G = NttGeom<LOGL>;
+    if constexpr (G::WAVE_OWNED && LOGL >= 4) {         // transforms of <= 2^4 points are one radix block: no stage twiddles
+#pragma unroll
+        for (int e = tid; e < G::L; e += NTT_THREADS) lds[G::TW_OFF + e] = tw_local[e << (NTT_LOCAL_MAX_LOG - LOGL)];
     }
 }
 
@@ -293,6 +330,7 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_col_pass(
         else x = glx_canon(v[q]);             // the caller's values may be any u64 representatives
         lds[G::at(t, i1)] = x;
     }
+    ntt_fill_lds_twiddles<LOGL>(lds, p.tw_local, tid);
     __syncthreads();
     if (!NTT_DBG(p, 1)) ntt_lds_stages<LOGL, 0, INV, ZP>(lds, p.tw_local, tid);
     if constexpr (G::WAVE_OWNED) __syncthreads();
@@ -365,6 +403,7 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_row_pass(
         }
         lds[G::at(r, i2)] = x;
     }
+    ntt_fill_lds_twiddles<LOGL>(lds, p.tw_local, tid);
     __syncthreads();
     if (!NTT_DBG(p, 1)) ntt_lds_stages<LOGL, 0, INV>(lds, p.tw_local, tid);
     if constexpr (G::WAVE_OWNED) __syncthreads();

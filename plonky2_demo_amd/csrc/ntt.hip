@@ -325,7 +325,7 @@ static int launch_col_impl(gl_ctx* c, const NttPassParams& p, dim3 grid) {
 template <int LOGL, bool INV>
 static int launch_col(gl_ctx* c, const NttPassParams& p, dim3 grid) {
     // zero-padded input (LDE with rate >= 8, forward only): the first radix stage sees one or two non-zero inputs per task
-    if constexpr (!INV && LOGL >= 5 && LOGL <= 10) {
+    if constexpr (!INV && LOGL >= 5 && LOGL <= 10 && ntt_first_radix(LOGL) <= 4) {
         const uint64_t N = uint64_t(1) << (p.lgN1 + p.lgN2);
         if ((uint64_t)p.n_in * 8 <= N) return launch_col_impl<LOGL, INV, true>(c, p, grid);
     }

@@ -235,6 +235,80 @@ static int h2d_async(gl_ctx* c, void* dst, const void* src, size_t bytes) {
     return GL_OK;
 }
 
+// Host witness -> HBM through a two-deep ring of pinned chunks (the drop-in entry points gl_prove / gl_prove_columns; reference side:
+// MatrixWitness.wire_values, iop/witness.rs:256-258, handed to PolynomialBatch::from_values at plonk/prover.rs:145-156).
+// A hipMemcpyAsync from PAGEABLE memory is staged by the runtime inside the call: the calling thread spins there until the
+// stream's earlier work is done and the copy is on its way (the round-2 finding for the D2H direction: a full core per proof in
+// flight).  Here the host thread copies the columns into one of two pinned chunks (plain memcpy, ~10 GB/s), hands the chunk to
+// the copy engine and fills the other one meanwhile; it only ever waits, sleeping between polls, for a chunk to come back.
+// The DMA of a proof's witness runs under the kernels of the other proofs in flight on the device's other contexts.
+static hipError_t gl_event_wait(hipEvent_t ev) {
+    hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(30)) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        } else { struct timespec ts = {0, 20000}; (void)nanosleep(&ts, nullptr); }
+    }
+}
+struct H2dRing {
+    gl_ctx* c; void* buf[2] = {nullptr, nullptr}; size_t cap[2] = {0, 0}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false};
+    explicit H2dRing(gl_ctx* ctx) : c(ctx) {}
+    int init(size_t chunk_bytes) {
+        for (int k = 0; k < 2; k++) {
+            GL_TRY(c->pin_acquire(chunk_bytes, &buf[k], &cap[k]));
+            GL_CHECK_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        }
+        return GL_OK;
+    }
+    int slot_free(int k) { if (busy[k]) { GL_CHECK_HIP(gl_event_wait(ev[k])); busy[k] = false; } return GL_OK; }
+    int send(int k, void* d_dst, size_t bytes) {
+        GL_CHECK_HIP(hipMemcpyAsync(d_dst, buf[k], bytes, hipMemcpyHostToDevice, c->stream));
+        GL_CHECK_HIP(hipEventRecord(ev[k], c->stream));
+        busy[k] = true;
+        return GL_OK;
+    }
+    ~H2dRing() {                  // a chunk goes back to the context's list only after the copy engine has read it
+        for (int k = 0; k < 2; k++) {
+            if (busy[k]) (void)gl_event_wait(ev[k]);
+            if (ev[k]) (void)hipEventDestroy(ev[k]);
+            if (buf[k]) c->pin_release(buf[k], cap[k]);
+        }
+    }
+};
+static const size_t GL_H2D_CHUNK = size_t(8) << 20;
+// cols != null: ncols host vectors of n elements each (d_dst[c * n + i] = cols[c][i]); else `flat`, ncols * n contiguous elements
+static int h2d_witness(gl_ctx* ctx, gl_t* d_dst, size_t ncols, size_t n, const uint64_t* const* cols, const uint64_t* flat) {
+    const size_t col_bytes = n * sizeof(gl_t), total = ncols * col_bytes;
+    if (!total) return GL_OK;
+    H2dRing ring(ctx);
+    GL_TRY(ring.init(total < GL_H2D_CHUNK ? total : GL_H2D_CHUNK));
+    const size_t chunk = ring.cap[0] < ring.cap[1] ? ring.cap[0] : ring.cap[1];
+    size_t off = 0; int k = 0;
+    while (off < total) {
+        const size_t len = total - off < chunk ? total - off : chunk;
+        GL_TRY(ring.slot_free(k));
+        if (!cols) memcpy(ring.buf[k], (const char*)flat + off, len);
+        else {
+            size_t done = 0;
+            while (done < len) {                        // a chunk may begin and end inside a column
+                const size_t c = (off + done) / col_bytes, in_col = (off + done) % col_bytes;
+                const size_t piece = (col_bytes - in_col) < (len - done) ? (col_bytes - in_col) : (len - done);
+                memcpy((char*)ring.buf[k] + done, (const char*)cols[c] + in_col, piece);
+                done += piece;
+            }
+        }
+        GL_TRY(ring.send(k, (char*)d_dst + off, len));
+        off += len; k ^= 1;
+    }
+    return GL_OK;                                       // ~H2dRing waits for the last two chunks (the DMA of <= 16 MiB)
+}
+
 // ======================================================================================================================
 // Phase-level entry points: the seam of SURVEY 8(b).  A caller that keeps the Fiat-Shamir transcript on its side (the
 // reference's Challenger in Rust) drives these one by one; gl_prove() below is exactly that driver with the transcript
@@ -658,15 +732,13 @@ extern "C" int gl_prove(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wi
 extern "C" int gl_prove_columns(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* const* h_wire_columns, const uint64_t* h_pis, size_t npis, gl_proof** out) {
     GL_REQUIRE(ctx && cir && h_wire_columns && out, GL_ERR_ARG, "gl_prove_columns: null argument");
     GL_TRY(ctx->activate());
-    const size_t n = cir->n;
-    DevBuf d_wit(ctx); GL_TRY(d_wit.alloc(135 * n * sizeof(gl_t)));
+    const size_t n = cir->n, nw = cir->desc.num_wires;
+    for (size_t c = 0; c < nw; c++) GL_REQUIRE(h_wire_columns[c], GL_ERR_ARG, "gl_prove_columns: null column");
+    DevBuf d_wit(ctx); GL_TRY(d_wit.alloc(nw * n * sizeof(gl_t)));
     ctx->timing_begin("H2D witness");
-    for (size_t c = 0; c < 135; c++) {
-        GL_REQUIRE(h_wire_columns[c], GL_ERR_ARG, "gl_prove_columns: null column");
-        GL_CHECK_HIP(hipMemcpyAsync(d_wit.as<gl_t>() + c * n, h_wire_columns[c], n * sizeof(gl_t), hipMemcpyHostToDevice, ctx->stream));
-    }
+    GL_TRY(h2d_witness(ctx, d_wit.as<gl_t>(), nw, n, h_wire_columns, nullptr));
     ctx->timing_end();
-    // pageable sources are staged by the runtime before each call returns; the proof is finished before d_wit is released
+    // the caller's vectors have been read when h2d_witness returns; the proof is finished before d_wit is released
     return prove_impl(ctx, cir, d_wit.as<uint64_t>(), true, h_pis, npis, nullptr, out);
 }
 extern "C" int gl_prove_device(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t* h_pis, size_t npis, gl_proof** out) {
@@ -698,7 +770,7 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     if (!wires_on_device) {
         GL_TRY(d_wit.alloc(135 * n * sizeof(gl_t)));
         ctx->timing_begin("H2D witness");
-        GL_CHECK_HIP(hipMemcpyAsync(d_wit.p, h_wires, 135 * n * sizeof(gl_t), hipMemcpyHostToDevice, st));
+        GL_TRY(h2d_witness(ctx, d_wit.as<gl_t>(), 135, n, nullptr, h_wires));
         ctx->timing_end();
         d_wires = d_wit.as<gl_t>();
     }

@@ -119,6 +119,45 @@ def test_ntt_extreme_values(gpu, orc):
             assert (p.lde_onto_coset(x, 3) == orc.lde(x, 3, threads=4)).all(), lg
 
 
+@pytest.mark.parametrize("lg", [4, 6, 8, 10, 12, 13, 16, 20])
+def test_ntt_structured_inputs(gpu, orc, lg):
+    # sparse and power-of-two columns: unit vectors, 2^k, h 2^(96-E), p - 2^k.  With such inputs a transform carries +-2^k through
+    # its layers, which is where the shift twiddles take their rare paths (x 2^E with a zero low and middle word: the borrow
+    # without carry of glx_shl_c, 32 < E < 64) that uniformly random columns reach with probability ~2^-32 per operation.
+    # Closed forms besides the oracle: fft(e_j)[i] = w^(i j), and fft of a constant column is (n c, 0, 0, ...).
+    p, ctx = gpu
+    n = 1 << lg
+    rng = np.random.default_rng(lg)
+    rows = []
+    for j in (0, 1, 2, n // 2, n - 1, int(rng.integers(0, n))):          # unit vectors (scaled by 1, 2^63, p - 1)
+        for c in (1, 2**63, P - 1):
+            v = np.zeros(n, dtype=np.uint64); v[j % n] = c; rows.append(v)
+    pw = np.array([(1 << int(k)) % P for k in rng.integers(0, 64, n)], dtype=np.uint64)
+    rows.append(pw)                                                          # every entry a power of two
+    rows.append(np.array([P - (1 << int(k)) for k in rng.integers(0, 64, n)], dtype=np.uint64))
+    hs = [(int(h) << (96 - E)) % 2**64 for E in (36, 48, 60) for h in (1, 3, 7, (1 << (E - 32)) - 1)]
+    rows.append(np.array([hs[int(i)] for i in rng.integers(0, len(hs), n)], dtype=np.uint64))
+    sp = np.zeros(n, dtype=np.uint64); sp[rng.integers(0, n, max(1, n // 64))] = 2**63; rows.append(sp)     # sparse
+    rows.append(np.full(n, 2**63, dtype=np.uint64))                          # constant column
+    x = np.stack(rows)
+    f = p.fft(x)
+    if lg <= 16:
+        assert (f == orc.fft(x)).all()
+        assert (p.ifft(x) == orc.ifft(x)).all()
+        assert (p.coset_fft(x, 7) == orc.coset_fft(x, 7)).all()
+    else:
+        assert (f[:2] == orc.fft(x[:2])).all() and (f[-4:] == orc.fft(x[-4:])).all()
+    assert (p.ifft(f) == x).all()
+    assert ints(f[0]) == [1] * n                                            # e_0 -> all ones
+    w = pow(7, (P - 1) >> lg, P) if lg else 1                               # the reference's primitive root of unity (fft.rs:14-33)
+    assert pow(w, n, P) == 1
+    if lg <= 12:
+        assert ints(f[3]) == [pow(w, i, P) for i in range(n)]              # e_1 -> w^i
+    assert int(f[-1][0]) == (n * 2**63) % P and not f[-1][1:].any()
+    if 3 <= lg <= 13:
+        assert (p.lde_onto_coset(x, 3) == orc.lde(x, 3, threads=4)).all()
+
+
 def test_ntt_2_20_against_oracle_and_round_trip(gpu, orc):
     # BASELINE config 2: 2^20-point forward + inverse, bit-exact vs field::fft on B = 2; properties on B = 8
     p, ctx = gpu
@@ -577,6 +616,24 @@ def test_hand_scheduled_primitives_against_int128(gpu):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "FAIL" not in r.stdout and r.stdout.count(": ok") == 3, r.stdout
+
+
+def test_goldilocks_primitives_edge_grid_against_int128(gpu):
+    # tools/ubench/gl_prims.hip: glx_mul / glx_mul3 (both canonicalisations), add_cc / sub_cc, the accumulator folds and EVERY branch of
+    # glx_shl_c (12, 24, 32, 36, 48, 60, 72, 84) on an edge grid that holds the boundary forms of each branch (2^k for all k, p - 2^k,
+    # h 2^(96-E), low bits zero) x itself plus random words, against unsigned __int128 on the host.  (this program
+    # was outside pytest, and profiles/r02_gl_primitives.txt held FAIL rows of a development build of the 32 < E < 64 branch.)
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "ubench", "bin", "gl_prims")
+    src = os.path.join(root, "tools", "ubench", "gl_prims.hip")
+    hdr = os.path.join(root, "plonky2_demo_amd", "csrc", "gl64_gfx950.cuh")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-w", "-I", os.path.join(root, "plonky2_demo_amd", "csrc"), src, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FAIL" not in r.stdout and "MISMATCH" not in r.stdout and "total mismatches: 0" in r.stdout, r.stdout
 
 
 def test_concurrent_proofs_on_shared_circuit_are_deterministic(gpu):

@@ -347,14 +347,20 @@ int main() {
     std::vector<uint64_t> ha, hb;
     const uint64_t edge[] = {0, 1, 2, P - 1, P, P + 1, 0xFFFFFFFFULL, 0x100000000ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL, 0xFFFFFFFEFFFFFFFFULL,
                              0x8000000000000000ULL, 0x7FFFFFFFFFFFFFFFULL, 0xFFFFFFFF, 0xFFFFFFFE00000001ULL, 0x00000001FFFFFFFFULL};
-    for (uint64_t x : edge) for (uint64_t y : edge) { ha.push_back(x); hb.push_back(y); }
+    // + the boundary forms of every glx_shl_c branch: 2^k for all k, h 2^(96-E) (x << E has a zero low word and a
+    // zero middle word: the borrow-without-carry case), low (64 - E) bits zero, p - 2^k
+    std::vector<uint64_t> grid(edge, edge + sizeof(edge) / sizeof(edge[0]));
+    for (int k = 0; k < 64; k++) { grid.push_back(1ULL << k); grid.push_back(P - (1ULL << k)); }
+    for (int E : {36, 48, 60}) for (uint64_t h : {1ULL, 3ULL, 7ULL, (1ULL << (E - 33)) + 1, (1ULL << (E - 32)) - 1}) grid.push_back(h << (96 - E));
+    for (int E : {12, 24, 36, 48, 60}) grid.push_back((0xFEDCBA9876543210ULL >> (64 - E)) << (64 - E));
+    for (uint64_t x : grid) for (uint64_t y : grid) { ha.push_back(x); hb.push_back(y); }
     uint64_t seed = 12345;
-    while (ha.size() < (1u << 16)) { ha.push_back(splitmix(seed)); hb.push_back(splitmix(seed)); }
+    while (ha.size() < (1u << 17)) { ha.push_back(splitmix(seed)); hb.push_back(splitmix(seed)); }
     const size_t n = ha.size();
     gl_t *da, *db, *dout, *din;
     hipMalloc((void**)&da, n * 8); hipMalloc((void**)&db, n * 8); hipMalloc((void**)&dout, (size_t)256 * 8 * 256 * 8 * 2); hipMalloc((void**)&din, 4096 * 8);
     hipMemcpy(da, ha.data(), n * 8, hipMemcpyHostToDevice); hipMemcpy(db, hb.data(), n * 8, hipMemcpyHostToDevice);
-    hipMemcpy(din, ha.data() + 256, 4096 * 8, hipMemcpyHostToDevice);
+    hipMemcpy(din, ha.data() + ha.size() - 4096, 4096 * 8, hipMemcpyHostToDevice);
     std::vector<uint64_t> ho(n);
     int bad_total = 0;
     std::vector<uint64_t> hac(ha), hbc(hb);
@@ -363,7 +369,7 @@ int main() {
     gl_t *dac, *dbc, *dinc;
     (void)hipMalloc((void**)&dac, n * 8); (void)hipMalloc((void**)&dbc, n * 8); (void)hipMalloc((void**)&dinc, 4096 * 8);
     (void)hipMemcpy(dac, hac.data(), n * 8, hipMemcpyHostToDevice); (void)hipMemcpy(dbc, hbc.data(), n * 8, hipMemcpyHostToDevice);
-    (void)hipMemcpy(dinc, hac.data() + 256, 4096 * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dinc, hac.data() + hac.size() - 4096, 4096 * 8, hipMemcpyHostToDevice);
     // canon_in: 0 = any representatives, 1 = b canonical, 2 = both canonical; canon_out: the result must be < p
     auto check2 = [&](const char* name, auto f, auto ref, int canon_in, bool canon_out) {
         const gl_t* pa = canon_in >= 2 ? dac : da; const gl_t* pb = canon_in >= 1 ? dbc : db;
