@@ -102,6 +102,23 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+def usable_cores():
+    """Cores this process can really burn: the smaller of the affinity mask and the cgroup's CPU quota (a 1-GPU box shows 256
+    cores in the mask and grants 16)."""
+    q = cpu_quota_cores()
+    n = float(host_cores())
+    return min(n, q) if q else n
+
+
+def lanes_per_rank(world, wanted):
+    """Every proof in flight has a host thread that drives its ~10 transcript round trips and polls its stream (~0.3 of a core
+    each once the waits sleep): with N ranks on one host the lanes of a rank are capped by the rank's share of the usable cores
+    (never below 4).  Returns (cores per rank, {name: (wanted, granted)})."""
+    per_rank = usable_cores() / max(1, world)
+    cap = max(4, int(per_rank))
+    return per_rank, {k: (v, min(v, cap)) for k, v in wanted.items()}
+
+
 def cpu_micro_rows(orc, oracle_lib, threads):
     """BASELINE.md section 3's CPU columns for the micro-kernel rows, on bounded samples (opt-in: --cpu-rows)."""
     import numpy as np
@@ -165,11 +182,6 @@ def cpu_baseline(m, rows=False, one_thread_full=False):
     # 1 thread (the reference binary's configuration, matrix_mul.rs:19): a full 1-thread proof takes minutes, so the parallel
     # speed-up is measured on a bounded sample of the same proof -- the Z / partial-products commitment (PolynomialBatch::
     # from_values of 20 columns x n, rate 3, cap 4: iFFT + LDE + Poseidon Merkle tree) -- with 1 thread and with all threads
-    n = 1 << oc.info["degree_bits"]
-    vals = oracle_lib.rand_field(66, (20, n))
-    t0 = time.perf_counter(); orc.batch(vals, 3, 4, from_values=True, threads=1); t1 = time.perf_counter() - t0
-    t0 = time.perf_counter(); orc.batch(vals, 3, 4, from_values=True, threads=threads); tn = time.perf_counter() - t0
-    speedup = t1 / tn
     micro = cpu_micro_rows(orc, oracle_lib, threads) if rows else None
     measured_1t = None
     if one_thread_full:                             # opt-in (--cpu-one-thread): one full proof on ONE thread, about a minute
@@ -178,14 +190,29 @@ def cpu_baseline(m, rows=False, one_thread_full=False):
     return {
         "value": 1.0 / med, "unit": "proofs/s", "cores": cores, "threads": threads, "cpu_quota_cores": cpu_quota_cores(), "kind": "port", "micro_kernel_rows": micro, "one_thread_measured": measured_1t,
         "runs_s": [round(t, 3) for t in times],
-        "one_thread": {"value": 1.0 / (med * speedup), "unit": "proofs/s", "derived": True,
-                       "sample_commit_1_thread_s": round(t1, 3), "sample_commit_all_threads_s": round(tn, 3), "parallel_speedup": round(speedup, 2)},
+        "one_thread": committed_one_thread(m),
         "sample": "all cores: median of %d full proofs (after one warm-up proof) of the m=%d circuit by the C++ restatement of the reference prover (oracle/gl_prover.hpp), "
-                  "%d threads on %d usable cores over the reference's Rayon axes, verifier restatement %s; 1 thread: the all-core figure "
-                  "divided by the parallel speed-up measured on the proof's 20-column x 2^%d commitment (from_values, rate 3, cap 4) -- a lower "
-                  "bound: a full 1-thread proof measured with --cpu-one-thread takes 45 s on the GPU box's host (profiles/r02_cpu_one_thread.json)"
-                  % (len(times), m, threads, cores, "accepts" if ok else "REJECTS", oc.info["degree_bits"]),
+                  "%d threads on %d cores of the affinity mask (cgroup quota: %s cores) over the reference's Rayon axes, verifier restatement %s; "
+                  "1 thread: not timed in the default run (a full 1-thread proof takes 45 s: --cpu-one-thread), `one_thread` quotes the committed measurement"
+                  % (len(times), m, threads, cores, cpu_quota_cores(), "accepts" if ok else "REJECTS"),
     }
+
+
+def committed_one_thread(m):
+    """The measured 1-thread figure of the CPU port (one full proof, --cpu-one-thread), as committed under profiles/: quoted, not
+    derived (round 2's derived figure was 1.8x off)."""
+    for name in ("r03_cpu_one_thread.json", "r02_cpu_one_thread.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if m == 64 and os.path.exists(path):
+            try:
+                d = json.load(open(path))
+                d = d.get("cpu_baseline", d)
+                d = d.get("one_thread_measured") or d
+                return {"value": d["value"], "unit": "proofs/s", "seconds": d.get("seconds"), "measured": True,
+                        "source": "profiles/%s (committed profile of `bench.py --cpu-one-thread`, not measured in this run)" % name}
+            except Exception:
+                pass
+    return None
 
 
 def timed_launches(ctx, fn, reps):
@@ -231,9 +258,23 @@ def ntt_leg(torch, ctx, lib, check, dev, batch, with_rows=True):
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "forward 2^20 NTT x %d polynomials = ntt_col_pass<10> + ntt_row_pass<10>" % batch,
-                "algorithmic_bytes": algo, "launches": launches,
-                "note": "VALU-issue-bound on gfx950 (no 64x64 multiplier, no 64-bit add with carry-out): ~330 VALU instructions per element over "
-                        "the two passes (SQ_INSTS_VALU, profiles/README.md); the memory-only time of the two passes is in profiles/"}
+                "algorithmic_bytes": algo, "launches": launches}
+    # the kernel's own roof is VALU issue (gfx950: no 64x64 multiplier, no 64-bit add with carry-out): instructions per element from the
+    # committed SQ_INSTS_VALU pass, one wave64 instruction per 4 cycles per SIMD at the nominal clock
+    vi_path = os.path.join(ROOT, "profiles", "ntt20_valu.json")
+    if os.path.exists(vi_path) and batch == 64:
+        try:
+            vi = json.load(open(vi_path))
+            per_elem = vi["valu_instructions_per_element"]["col"] + vi["valu_instructions_per_element"]["row"]
+            peak = 256 * 4 * VALU_CLOCK_HZ / 4.0
+            roofline["valu_frac"] = per_elem * batch * L / 64.0 / peak / (fwd_ms * 1e-3)
+            roofline["valu"] = {"instructions_per_element": per_elem, "peak_wave_instructions_per_s": peak,
+                                "source": "profiles/ntt20_valu.json: SQ_INSTS_VALU of tools/prof_ntt.py (committed profile, not measured in this run); "
+                                          "peak = 1024 SIMDs x %.1f GHz / 4 cycles per wave64 instruction" % (VALU_CLOCK_HZ / 1e9)}
+            roofline["note"] = ("VALU-issue-bound: %.0f VALU instructions per element over the two passes (SQ_INSTS_VALU); "
+                                "the memory-only / VALU-only times of the passes and the variants tried are in profiles/README.md" % per_elem)
+        except Exception:
+            pass
     ntt = {"metric": "Goldilocks NTT GF-elems/sec at 2^20 (forward+inverse)", "value": reps * 2.0 * batch * L / dt, "unit": "GF-elems/s",
            "batch": batch, "round_trip_bit_exact": intact}
     # the two reference points SURVEY 8(d) asks for next to the roofline fraction: a measured device copy (what "HBM-bound"
@@ -355,6 +396,9 @@ def main():
     ap.add_argument("--e2e-steps", type=int, default=160, help="proofs of the secondary run that also times witness generation (0 = skip)")
     ap.add_argument("--e2e-lanes", type=int, default=0, help="proofs in flight of the secondary run (default: --streams)")
     ap.add_argument("--config4", action="store_true", help="BASELINE configs[3]: one batch of --batch proofs sharded over the ranks (strong scaling)")
+    ap.add_argument("--host-witness", action="store_true", help="with --config4: the witnesses are full host matrices (135 vectors of n, as the reference holds them) "
+                    "and go through gl_prove_columns: the 35 MB H2D per proof is inside the clock (SURVEY 8d: 'incl. H2D of witnesses')")
+    ap.add_argument("--host-witness-steps", type=int, default=160, help="proofs of the secondary run through gl_prove_columns (host witness, H2D in the clock; 0 = skip)")
     ap.add_argument("--batch", type=int, default=512, help="proofs of the config-4 batch")
     ap.add_argument("--pool-lanes", type=int, default=16, help="proofs in flight per GPU in the config-4 batch")
     ap.add_argument("--spawn", action="store_true", help="run even a 1-GPU job as a spawned rank over RCCL (the N > 1 code path)")
@@ -397,16 +441,12 @@ def main():
 
     # every proof in flight has a host thread that drives its ~10 transcript round trips (and polls its stream): with N ranks on
     # one host the lanes per rank are capped by the rank's share of the usable cores (never below 4)
-    try:
-        cores_per_rank = max(1, len(os.sched_getaffinity(0)) // max(1, world))
-    except AttributeError:
-        cores_per_rank = max(1, (os.cpu_count() or 1) // max(1, world))
-    for name in ("streams", "pool_lanes"):
-        want = getattr(args, name)
-        if want > max(4, cores_per_rank):
-            setattr(args, name, max(4, cores_per_rank))
+    cores_per_rank, lane_caps = lanes_per_rank(world, {"streams": args.streams, "pool_lanes": args.pool_lanes})
+    for name, (want, got) in lane_caps.items():
+        if got != want:
+            setattr(args, name, got)
             if rank == 0:
-                sys.stderr.write("bench.py: --%s %d -> %d (%d usable cores per rank)\n" % (name.replace("_", "-"), want, getattr(args, name), cores_per_rank))
+                sys.stderr.write("bench.py: --%s %d -> %d (%.1f usable cores per rank: min(affinity mask, cgroup quota) / ranks)\n" % (name.replace("_", "-"), want, got, cores_per_rank))
 
     import plonky2_demo_amd as p
     from plonky2_demo_amd import sharding
@@ -454,8 +494,78 @@ def main():
             dt = float(tt.item())
         return dt, nbytes, ok
 
+    def host_witness_run(cd_or_views, count, nl, nwit, seed0):
+        """`count` proofs through gl_prove_columns on `nl` lanes: every proof's 135 host vectors (35 MB at m = 64) cross PCIe inside the
+        clock.  Returns (seconds, host CPU seconds of the whole process, proofs, HostColumns used)."""
+        hw = []
+        for k in range(nwit):
+            a, b = operands(seed0 + k)
+            wires, pis = hc.witness(a, b, filler_seed=seed0 + k)
+            hw.append((p.api.HostColumns([wires[c] for c in range(135)], hc.n), pis))
+        res = [None] * count
+
+        def work(lane, n_):
+            for i in range(lane, n_, nl):
+                cols, pis = hw[i % nwit]
+                res[i] = cd_or_views[lane][1].prove_columns(cols, pis)
+            cd_or_views[lane][0].synchronize()
+
+        for n_ in (nl, count):                               # warm-up round (pinned chunks, pools), then the timed one
+            barrier()
+            c0 = time.process_time()
+            t0 = time.perf_counter()
+            ths = [threading.Thread(target=work, args=(k, n_)) for k in range(nl)]
+            [th.start() for th in ths]
+            [th.join() for th in ths]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            cpu = time.process_time() - c0
+        return dt, cpu, res, hw
+
     common = {"unit": "proofs/s", "n_gpus": world, "higher_is_better": True, "vs_baseline": None,
-              "dtype": "u64 (Goldilocks, 64-bit modular integer)", "data": "synthetic"}
+              "dtype": "u64 (Goldilocks, 64-bit modular integer)", "data": "synthetic",
+              "host": {"lanes_per_gpu": args.streams, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "cores_affinity": host_cores(), "cpu_quota_cores": cpu_quota_cores(), "usable_cores_per_rank": usable_cores() / max(1, world)}}
+    import threading
+
+    if args.config4 and args.host_witness:
+        # BASELINE configs[3] as SURVEY 8d words it: wall clock incl. the H2D of the witnesses.  Proof i on rank i mod N, each rank
+        # drives its lanes through gl_prove_columns from full host witness matrices (cycled from 16 distinct ones), then the cap gather.
+        mine = sharding.proofs_for_rank(args.batch, rank, world)
+        cd4 = hc.build(ctx)
+        nl = max(1, args.pool_lanes)
+        views = [(ctx, cd4)] + [(lambda c: (c, p.api.CircuitView(cd4, c)))(p.Context(device=local_rank)) for _ in range(nl - 1)]
+        if use_dist:
+            sharding.gather_caps(np.zeros((len(mine), 3, 16, 4), dtype=np.uint64), args.batch, device=dev)
+        cpu0 = time.process_time()
+        dt, cpu_s, res, hw = host_witness_run(views, len(mine), nl, 16, 5000 * rank)
+        t1 = time.perf_counter()
+        caps = np.stack([pr.caps() for pr in res]) if res else np.zeros((0, 3, 16, 4), dtype=np.uint64)
+        allcaps = sharding.gather_caps(caps, args.batch, device=dev) if use_dist else caps
+        barrier()
+        dt += time.perf_counter() - t1
+        assert allcaps.shape == (args.batch, 3, 16, 4) and (allcaps[rank::world] == caps).all()
+        ok = all(cd4.verify(res[i])[0] for i in range(0, len(res), max(1, len(res) // nl)))       # one proof per lane's worth, after the clock
+        if use_dist:
+            tt = torch.tensor([dt, cpu_s], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt, cpu_s = float(tt[0].item()), float(tt[1].item())
+        if rank == 0:
+            out = dict(common)
+            out.update({
+                "metric": "proofs/sec for m=64 matmul circuit, batch of %d independent proofs from HOST witness matrices sharded over the GPUs (BASELINE configs[3], incl. H2D)" % args.batch,
+                "value": args.batch / dt, "steps": args.batch, "warmup": nl, "ms_per_step": dt / args.batch * 1e3, "scaling": "strong",
+                "config": {"workload": "prove_matmul_m%d_batch%d_host_witness" % (m, args.batch), "proof_bytes": len(res[0].to_bytes()),
+                           "proofs_in_flight_per_gpu": nl, "entry_point": "gl_prove_columns (135 host vectors of n per proof, %.1f MB, pageable memory)" % (135 * hc.n * 8 / 1e6),
+                           "includes": "H2D of every witness through the library's pinned ring, prove(), RCCL all_gather of the Merkle caps",
+                           "sampled_proofs_verify": bool(ok), "host_cpu_seconds_per_proof_max_rank": cpu_s / max(1, len(mine)),
+                           "parallelism": "proof i on rank i mod N; no data-path collective"},
+                "roofline": None, "cpu_baseline": None})
+            print(json.dumps(out))
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if args.config4:
         dt, nbytes, ok = run_config4(args.batch, args.pool_lanes)
@@ -476,7 +586,6 @@ def main():
 
     cd = hc.build(ctx)                                    # circuit data replicated on every GPU
     # independent proofs overlap on separate streams (the transcript forces ~10 host syncs inside one proof)
-    import threading
     nstreams = max(1, args.streams)
     lanes = [(ctx, cd)] + [(lambda c: (c, p.api.CircuitView(cd, c)))(p.Context(device=local_rank)) for _ in range(nstreams - 1)]
     wit = []
@@ -493,11 +602,16 @@ def main():
         t, pis = wit[i % len(wit)]
         return lanes[lane][1].prove_device(ctypes.c_void_p(t.data_ptr()), pis)
 
+    last_proof = [None] * nstreams                      # the last proof of every lane: verified AFTER the clock stops
+
     def run_steps(first, count, sink):
         """`count` proofs, round-robin over the lanes, one host thread per lane (ctypes releases the GIL)."""
         def work(lane):
+            pr = None
             for i in range(first + lane, first + count, nstreams):
-                sink[i - first] = step(i, lane).caps()
+                pr = step(i, lane)
+                sink[i - first] = pr.caps()
+            last_proof[lane] = pr
             lanes[lane][0].synchronize()
         ths = [threading.Thread(target=work, args=(k,)) for k in range(nstreams)]
         for th in ths:
@@ -517,8 +631,10 @@ def main():
             use_dist = False
     barrier()
     caps = [None] * nproofs
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     run_steps(0, nproofs, caps)
+    cpu_timed = time.process_time() - cpu0
     gathered = None
     if use_dist:                                            # the Merkle-cap gather: 3 x 16 x 32 B per proof
         # rank r proved global proofs r, r + world, ... (round-robin); every rank ends with all caps in proof order
@@ -533,6 +649,8 @@ def main():
         assert (gathered[rank::world] == np.stack(caps)).all()
 
     proof_bytes = len(step(0).to_bytes())
+    lanes_verified = sum(1 for pr in last_proof if pr is not None and cd.verify(pr)[0])      # one proof per lane out of the timed loop
+    lanes_with_proofs = sum(1 for pr in last_proof if pr is not None)
     if rank == 0:
         value = world * nproofs / dt
         # secondary figure (not `value`): the same loop with witness generation inside the clock -- operands on the host,
@@ -568,6 +686,18 @@ def main():
                    "proofs_in_flight": nl,
                    "includes": "witness generation from host operands (GPU arithmetic rows + host hash-sponge rows) + prove()"}
             del gens, bufs, el
+        # secondary figure (not `value`): the drop-in host path.  gl_prove_columns from full HOST witness matrices (135 pageable
+        # vectors per proof, as plonk/prover.rs:145 holds them): 35 MB cross PCIe per proof inside the clock
+        hostw = None
+        if args.host_witness_steps > 0 and world == 1:
+            hw_dt, hw_cpu, hw_res, _hw = host_witness_run(lanes, args.host_witness_steps, nstreams, 4, 900)
+            same = hw_res[0].to_bytes() == lanes[0][1].prove_device(ctypes.c_void_p(torch.from_numpy(np.stack(_hw[0][0].cols).view(np.int64)).to(dev).data_ptr()), _hw[0][1]).to_bytes()
+            hostw = {"value": args.host_witness_steps / hw_dt, "unit": "proofs/s", "proofs": args.host_witness_steps, "proofs_in_flight": nstreams,
+                     "ms_per_proof": hw_dt / args.host_witness_steps * 1e3, "frac_of_resident_witness_rate": args.host_witness_steps / hw_dt / value,
+                     "host_cpu_seconds_per_proof": hw_cpu / args.host_witness_steps, "h2d_bytes_per_proof": 135 * hc.n * 8,
+                     "pcie_GBs": 135 * hc.n * 8 * args.host_witness_steps / hw_dt / 1e9, "bytes_equal_to_prove_device": bool(same),
+                     "entry_point": "gl_prove_columns: 135 pageable host vectors per proof -> two-deep pinned ring -> HBM, then prove()"}
+            del hw_res, _hw
         # the roofline kernel (forward 2^20 NTT x 64) and the Poseidon ceiling always run; --no-extra skips the other micro-kernel rows
         roofline, ntt, extra, perm_ceiling = ntt_leg(torch, ctx, lib, check, dev, args.ntt_batch, with_rows=not args.no_extra)
         ctx.timing(True)
@@ -591,7 +721,11 @@ def main():
             "extra": extra,
             "prove_device_ms_by_scope": scopes,
             "with_witness_generation": e2e,
+            "with_host_witness": hostw,
         })
+        out["config"]["lanes_verified_after_the_clock"] = "%d of %d" % (lanes_verified, lanes_with_proofs)
+        out["host"]["cpu_seconds_timed_region_rank0"] = round(cpu_timed, 3)
+        out["host"]["cpu_seconds_per_proof_rank0"] = cpu_timed / max(1, nproofs)
         if perm_ceiling:
             perms = permutations_per_proof(hc.n)
             per_gpu = value / world
@@ -625,6 +759,11 @@ def main():
                                        "proofs_in_flight": args.pool_lanes, "first_proof_verifies": bool(c4_ok),
                                        "includes": "operands from host memory, witness generation in HBM, prove(); the multi-GPU form is `bench.py --gpus N --config4`"}
         out["cpu_baseline"] = cpu_baseline(m, rows=args.cpu_rows, one_thread_full=args.cpu_one_thread) if (world == 1 and not args.no_cpu) else None
+        if out["cpu_baseline"]:
+            # BASELINE.md publishes no number for this metric: the ratio below is against the CPU PORT timed in this run (kind "port"),
+            # a reported baseline and not a kernel-quality figure (the roofline fractions are)
+            out["vs_baseline"] = value / out["cpu_baseline"]["value"]
+            out["vs_baseline_is"] = "value / cpu_baseline.value (kind: port, %d threads)" % out["cpu_baseline"]["threads"]
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -472,6 +472,25 @@ def _prove_device(ctx, circuit_handle, n, d_wires_ptr, public_inputs, public_inp
     return Proof(h.value, n)
 
 
+class HostColumns:
+    """135 host vectors of n field elements with their pointer table (what a Rust caller passes as `*const *const u64`); built
+    once so that a timed loop measures gl_prove_columns, not numpy."""
+
+    def __init__(self, columns, n):
+        self.cols = [np.ascontiguousarray(_u64(c)) for c in columns]
+        if len(self.cols) != 135 or any(c.size != n for c in self.cols):
+            raise ValueError("need 135 columns of n values")
+        self.ptrs = (ctypes.c_void_p * 135)(*[c.ctypes.data for c in self.cols])
+
+
+def _prove_columns(ctx, circuit_handle, n, columns, public_inputs):
+    hc = columns if isinstance(columns, HostColumns) else HostColumns(columns, n)
+    pis = _u64(public_inputs)
+    h = ctypes.c_void_p()
+    check(lib.gl_prove_columns(ctx.handle, circuit_handle, hc.ptrs, _p(pis), pis.size, ctypes.byref(h)))
+    return Proof(h.value, n)
+
+
 class CircuitData:
     """plonky2::plonk::circuit_data::CircuitData for the prover: `prove(wires, public_inputs)` mirrors
     CircuitData::prove (circuit_data.rs:144-151) at the full-witness boundary."""
@@ -538,15 +557,9 @@ class CircuitData:
         return Proof(h.value, self.host.n)
 
     def prove_columns(self, columns, public_inputs):
-        """prove() from one host array per wire, as the reference keeps MatrixWitness.wire_values."""
-        cols = [np.ascontiguousarray(_u64(c)) for c in columns]
-        if len(cols) != 135 or any(c.size != self.host.n for c in cols):
-            raise ValueError("need 135 columns of n values")
-        pis = _u64(public_inputs)
-        ptrs = (ctypes.c_void_p * 135)(*[c.ctypes.data for c in cols])
-        h = ctypes.c_void_p()
-        check(lib.gl_prove_columns(self.ctx.handle, self.handle, ptrs, _p(pis), pis.size, ctypes.byref(h)))
-        return Proof(h.value, self.host.n)
+        """prove() from one host array per wire, as the reference keeps MatrixWitness.wire_values (iop/witness.rs:256-258):
+        the drop-in entry INTEGRATION.md patches into plonk/prover.rs:145.  `columns` may be a HostColumns (pointer table built once)."""
+        return _prove_columns(self.ctx, self.handle, self.host.n, columns, public_inputs)
 
     def prove_device(self, d_wires_ptr, public_inputs, public_inputs_hash=None):
         """prove() with the witness matrix already in HBM (raw device pointer to [135][n] u64)."""
@@ -730,6 +743,9 @@ class CircuitView:
         h = ctypes.c_void_p()
         check(lib.gl_prove(self.ctx.handle, self.cd.handle, _p(wires), _p(pis), pis.size, ctypes.byref(h)))
         return Proof(h.value, self.cd.host.n)
+
+    def prove_columns(self, columns, public_inputs):
+        return _prove_columns(self.ctx, self.cd.handle, self.cd.host.n, columns, public_inputs)
 
 
 class FriProver:

@@ -33,10 +33,18 @@
 #define NTT_WAVES_PER_SIMD (NTT_THREADS / 64 / 4 * 2)  // two workgroups per CU (LDS)
 #endif
 #define NTT_LOCAL_MAX_LOG 12            // largest in-LDS transform
+#ifndef NTT_COL_DIRECT
+#define NTT_COL_DIRECT 1
+#endif
+#ifndef NTT_TWPASS_HALVES
+#define NTT_TWPASS_HALVES 1
+#endif
 #ifdef NTT_ABLATION
 #define NTT_DBG(p, bit) ((p).debug & (bit))
+#define NTT_ABLATION_BUILD 1            // the diagnostic build keeps the staged loads, whose pieces it can switch off
 #else
 #define NTT_DBG(p, bit) 0
+#define NTT_ABLATION_BUILD 0
 #endif
 #define NTT_SPLIT_LOG 11                // two-level power tables: x^e = lo[e & 2047] * hi[e >> 11]
 
@@ -279,6 +287,62 @@ __device__ __forceinline__ void ntt_lds_stages(gl_t* lds, const gl_t* __restrict
     }
 }
 
+// First Stockham stage of a wave-owned tile with its inputs taken straight from global memory (`load(t, i)` = point i of column
+// t of the tile as stored, `fix(t, i, v)` = its canonical, pre-scaled value: two steps, so that all loads are in flight together), instead of from a tile that was first staged through LDS: one LDS round trip and -- in the row pass,
+// where a wave reads its own rows -- the workgroup barrier in front of the first stage go away.  CROSS: tasks are dealt so that
+// consecutive lanes take consecutive COLUMNS (the column pass: a row of T columns is one contiguous global segment); otherwise
+// consecutive lanes take consecutive points of one column (the row pass: rows are contiguous).  The outputs land at their
+// Stockham positions; the caller synchronises (workgroup barrier: the twiddle table, and with CROSS the columns, were written by
+// other waves) and continues with ntt_lds_stages<LOGL, first radix>.
+template <int LOGL, bool INV, bool ZP, bool CROSS, class LOAD, class FIX>
+__device__ __forceinline__ void ntt_first_stage_direct(gl_t* lds, int tid, LOAD load, FIX fix) {
+    using G = NttGeom<LOGL>;
+    static_assert(G::WAVE_OWNED, "direct first stage: wave-owned tiles only");
+    constexpr int LOGR = ntt_first_radix(LOGL);
+    constexpr int R = 1 << LOGR;
+    constexpr int TPT = NTT_EPT / R;
+    constexpr int LOGJ = LOGL - LOGR;
+    constexpr int RIN = ZP ? R / 8 : R;
+    static_assert(!ZP || LOGR >= 3, "zero-padded first stage needs radix >= 8");
+    gl_t u[TPT][R];
+    int tcol[TPT], tj[TPT];
+#pragma unroll
+    for (int q = 0; q < TPT; q++) {
+        if constexpr (CROSS) {
+            const int task = tid + NTT_THREADS * q;
+            tcol[q] = task & (G::T - 1);
+            tj[q] = task >> G::LOGT;
+        } else {
+            constexpr int CPW = G::T / (NTT_THREADS / 64);
+            const int wave = tid >> 6, lane = tid & 63;
+            const int w_task = lane + 64 * q;
+            tcol[q] = wave * CPW + (w_task >> LOGJ);
+            tj[q] = w_task & ((1 << LOGJ) - 1);
+        }
+#pragma unroll
+        for (int r = 0; r < RIN; r++) u[q][r] = load(tcol[q], tj[q] + (r << LOGJ));     // every request goes out before the first use
+    }
+#pragma unroll
+    for (int q = 0; q < TPT; q++) {
+#pragma unroll
+        for (int r = 0; r < RIN; r++) u[q][r] = fix(tcol[q], tj[q] + (r << LOGJ), u[q][r]);
+    }
+#pragma unroll
+    for (int q = 0; q < TPT; q++) {
+        const int j0 = tj[q] << LOGR;
+        if constexpr (ZP) {
+            gl_t outv[R];
+            ntt_zp_first_all<R, INV, 0>(u[q][0], u[q][1], outv);
+#pragma unroll
+            for (int o = 0; o < R; o++) lds[G::at(tcol[q], j0 + o)] = outv[o];
+        } else {
+            ntt_small_dft<LOGR, INV>(u[q]);
+#pragma unroll
+            for (int o = 0; o < R; o++) lds[G::at(tcol[q], j0 + o)] = u[q][ntt_bitrev(o, LOGR)];
+        }
+    }
+}
+
 // w_L^e, e < L, into the LDS table behind a wave-owned tile (visible after the workgroup barrier that follows the tile load)
 template <int LOGL>
 __device__ __forceinline__ void ntt_fill_lds_twiddles(gl_t* lds, const gl_t* __restrict__ tw_local, int tid) {
@@ -294,22 +358,43 @@ __device__ __forceinline__ void ntt_fill_lds_twiddles(gl_t* lds, const gl_t* __r
 __device__ __forceinline__ gl_t ntt_ld(const gl_t* base, uint32_t i) { return *(const gl_t*)((const char*)base + (i << 3)); }
 __device__ __forceinline__ void ntt_st(gl_t* base, uint32_t i, gl_t x) { *(gl_t*)((char*)base + (i << 3)) = x; }
 
-// COLUMN pass (pass A).  grid = (N2 / T, batch).
-template <int LOGL, bool INV, bool ZP = false>
-__global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_col_pass(NttPassParams p) {
+// One workgroup per tile, deliberately NOT persistent: workgroups that walk several tiles (grid = what is resident, stage twiddles
+// staged once, stores draining under the next tile's loads) were built and measured in round 3 at 0.74 ms against 0.63 ms for the
+// 2^20 x 64 transform -- started together and doing equal work, the two workgroups of a CU stay in phase (both in their memory
+// phase, then both in their butterflies); the hardware dispatcher's one-in-one-out replacement keeps them apart, a start-up
+// stagger of half a tile does not (profiles/README.md).
+
+// COLUMN pass (pass A).  grid = (N2 / T, batch): T adjacent columns of one polynomial per workgroup.
+template <int LOGL, bool INV, bool ZP>
+__device__ __forceinline__ void ntt_col_tile(const NttPassParams& p, gl_t* lds, const int tid, const uint32_t bx, const uint32_t b) {
     using G = NttGeom<LOGL>;
     constexpr int LOGT = G::LOGT, T = G::T;
-    extern __shared__ __align__(16) gl_t lds[];
-    const int tid = threadIdx.x;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so give
     // XCD x a contiguous run of column tiles: neighbouring tiles share 128-byte lines when T*8 < 128.
-    uint32_t tile = blockIdx.x;
-    if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    uint32_t tile = bx;
+    if ((gridDim.x & 7) == 0) tile = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
     const uint32_t c0 = tile << LOGT;
-    const uint32_t b = blockIdx.y;
     const uint32_t lgN2 = p.lgN2;
     const gl_t* src = p.src + (uint64_t)b * p.src_stride;
     gl_t* dst = p.dst + (uint64_t)b * p.dst_stride;
+    if constexpr (G::WAVE_OWNED && !NTT_ABLATION_BUILD && NTT_COL_DIRECT) {
+        // wave-owned tiles: the first radix stage reads its inputs straight from global memory (lanes across the T columns)
+        ntt_fill_lds_twiddles<LOGL>(lds, p.tw_local, tid);
+        const uint32_t n_in = p.n_in;
+        const gl_t* pre_lo = p.pre_lo; const gl_t* pre_hi = p.pre_hi;
+        ntt_first_stage_direct<LOGL, INV, ZP, true>(lds, tid,
+            [&](int t, int i1) -> gl_t {
+                const uint32_t i = ((uint32_t)i1 << lgN2) + c0 + (uint32_t)t;
+                return (i < n_in) ? ntt_ld(src, i) : (gl_t)0;
+            },
+            [&](int t, int i1, gl_t v) -> gl_t {
+                const uint32_t i = ((uint32_t)i1 << lgN2) + c0 + (uint32_t)t;
+                if (pre_lo && i < n_in) return glx_mul<true>(v, ntt_pow2level(pre_lo, pre_hi, i));
+                return glx_canon(v);                  // the caller's values may be any u64 representatives
+            });
+        __syncthreads();
+        ntt_lds_stages<LOGL, ntt_first_radix(LOGL), INV, ZP>(lds, p.tw_local, tid);
+    } else {
     // load: e -> (i1 = e / T, t = e % T), zero beyond n_in; with ZP rows >= L/8 are known zeros and never touched
     constexpr int QLOAD = ZP ? NTT_EPT / 8 : NTT_EPT;
     gl_t v[QLOAD];
@@ -333,6 +418,7 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_col_pass(
     ntt_fill_lds_twiddles<LOGL>(lds, p.tw_local, tid);
     __syncthreads();
     if (!NTT_DBG(p, 1)) ntt_lds_stages<LOGL, 0, INV, ZP>(lds, p.tw_local, tid);
+    }
     if constexpr (G::WAVE_OWNED) __syncthreads();
     // store with the inter-pass twiddle w_N^(i2*k1); the products go three at a time
     const gl_t* tw_pass = p.tw_pass;
@@ -345,6 +431,23 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_col_pass(
         tw = tw_pass ? ntt_ld(tw_pass, o) : ntt_pow2level(p.tw_lo, p.tw_hi, i2 * k1);
     };
     constexpr int QG = NTT_EPT / 3 * 3;
+    if (tw_pass && NTT_TWPASS_HALVES) {
+        // all of the thread's inter-pass twiddles are requested before the first product: two memory latencies per tile instead of
+        // one per group of three (all sixteen at once made the compiler spill: it hoists the loads above the last stage)
+        constexpr int HALF = NTT_EPT / 2, HG = HALF / 3 * 3;
+#pragma unroll 1
+        for (int h = 0; h < NTT_EPT; h += HALF) {
+            gl_t x[HALF], tw[HALF]; uint32_t o[HALF];
+#pragma unroll
+            for (int q = 0; q < HALF; q++) elem(h + q, x[q], tw[q], o[q]);
+#pragma unroll
+            for (int q = 0; q < HG; q += 3) glx_mul3<true>(x[q], tw[q], x[q + 1], tw[q + 1], x[q + 2], tw[q + 2], x[q], x[q + 1], x[q + 2]);
+#pragma unroll
+            for (int q = HG; q < HALF; q++) x[q] = glx_mul<true>(x[q], tw[q]);
+#pragma unroll
+            for (int q = 0; q < HALF; q++) if (!NTT_DBG(p, 4) || x[q] == 12345) ntt_st(dst, o[q], x[q]);
+        }
+    } else {
 #pragma unroll 1
     for (int q = 0; q < QG; q += 3) {
         gl_t x[3], tw[3]; uint32_t o[3];
@@ -361,24 +464,38 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_col_pass(
         x = glx_mul<true>(x, tw);
         if (!NTT_DBG(p, 4) || x == 12345) ntt_st(dst, o, x);
     }
+    }
+}
+template <int LOGL, bool INV, bool ZP = false>
+__global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_col_pass(NttPassParams p) {
+    extern __shared__ __align__(16) gl_t lds[];
+    ntt_col_tile<LOGL, INV, ZP>(p, lds, threadIdx.x, blockIdx.x, blockIdx.y);
 }
 
 // ROW pass (pass B, or the only pass when lgN1 == 0).
 //   two-pass:   grid = (N1 / T, batch): rows k1 of one polynomial
 //   single:     grid = (ceil(batch / T), 1): T polynomials
 template <int LOGL, bool INV, bool SINGLE>
-__global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_row_pass(NttPassParams p) {
+__device__ __forceinline__ void ntt_row_tile(const NttPassParams& p, gl_t* lds, const int tid, const uint32_t bx, const uint32_t by) {
     using G = NttGeom<LOGL>;
     constexpr int LOGT = G::LOGT, T = G::T, L = G::L;
-    extern __shared__ __align__(16) gl_t lds[];
-    const int tid = threadIdx.x;
     constexpr bool single = SINGLE;                         // == (p.lgN1 == 0)
-    uint32_t tile = blockIdx.x;
-    if (!single && (gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    uint32_t tile = bx;
+    if (!single && (gridDim.x & 7) == 0) tile = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
     const uint32_t r0 = tile << LOGT;                       // first row (k1) or first polynomial
-    const uint32_t b = single ? 0 : blockIdx.y;
+    const uint32_t b = single ? 0 : by;
     const gl_t* src = p.src + (uint64_t)b * p.src_stride;
     gl_t* dst = p.dst + (uint64_t)b * p.dst_stride;
+    if constexpr (G::WAVE_OWNED && !SINGLE && !NTT_ABLATION_BUILD) {
+        // second pass over wave-owned rows: every wave reads its own rows (contiguous, canonical: the column pass wrote them)
+        // straight into the registers of the first radix stage
+        ntt_fill_lds_twiddles<LOGL>(lds, p.tw_local, tid);
+        ntt_first_stage_direct<LOGL, INV, false, false>(lds, tid,
+            [&](int t, int i2) -> gl_t { return ntt_ld(src, ((r0 + (uint32_t)t) << LOGL) + (uint32_t)i2); },
+            [](int, int, gl_t v) -> gl_t { return v; });
+        __syncthreads();
+        ntt_lds_stages<LOGL, ntt_first_radix(LOGL), INV>(lds, p.tw_local, tid);
+    } else {
     // load: e -> (r = e / L, i2 = e % L): contiguous rows
     gl_t v[NTT_EPT];
 #pragma unroll
@@ -406,6 +523,7 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_row_pass(
     ntt_fill_lds_twiddles<LOGL>(lds, p.tw_local, tid);
     __syncthreads();
     if (!NTT_DBG(p, 1)) ntt_lds_stages<LOGL, 0, INV>(lds, p.tw_local, tid);
+    }
     if constexpr (G::WAVE_OWNED) __syncthreads();
     if (single) {
         // store rows contiguously: e -> (r = e / L, k = e % L)
@@ -435,6 +553,11 @@ __global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_row_pass(
             if (!NTT_DBG(p, 4) || x == 12345) ntt_st(dst, k, x);
         }
     }
+}
+template <int LOGL, bool INV, bool SINGLE>
+__global__ __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) void ntt_row_pass(NttPassParams p) {
+    extern __shared__ __align__(16) gl_t lds[];
+    ntt_row_tile<LOGL, INV, SINGLE>(p, lds, threadIdx.x, blockIdx.x, blockIdx.y);
 }
 
 // out_lo[j] = base^j (j < 2^SPLIT), out_hi[j] = scale * base^(j << SPLIT) (j < hi_len)

@@ -37,3 +37,29 @@ def test_permutation_count_of_the_m64_proof():
     fri = sum((1 << lg) * 5 - 16 for lg in (14, 10, 6))     # three arity-16 reduction rounds (k_fri_fold x 3 in the profiles): 32-element leaves
     assert b.permutations_per_proof(n) == trees + fri + N + (1 << 16)
     assert b.permutations_per_proof(n) == 6968544            # the figure roofline_prove quotes
+
+
+def test_lanes_are_capped_by_the_cgroup_quota_not_the_affinity_mask(monkeypatch):
+    # the 1-GPU box: 256 cores in the affinity mask, a 16-core CFS quota.  Eight ranks x 16 lanes would need ~38 cores of polling
+    # threads: the cap is min(mask, quota) / world, never below 4
+    b = _bench_module()
+    monkeypatch.setattr(b, "host_cores", lambda: 256)
+    monkeypatch.setattr(b, "cpu_quota_cores", lambda: 16.0)
+    assert b.usable_cores() == 16.0
+    per, caps = b.lanes_per_rank(1, {"streams": 16, "pool_lanes": 16})
+    assert per == 16.0 and caps == {"streams": (16, 16), "pool_lanes": (16, 16)}
+    per, caps = b.lanes_per_rank(8, {"streams": 16, "pool_lanes": 16})
+    assert per == 2.0 and caps["streams"] == (16, 4) and caps["pool_lanes"] == (16, 4)
+    monkeypatch.setattr(b, "cpu_quota_cores", lambda: None)          # no quota: the mask counts
+    per, caps = b.lanes_per_rank(8, {"streams": 16})
+    assert per == 32.0 and caps["streams"] == (16, 16)
+    monkeypatch.setattr(b, "cpu_quota_cores", lambda: 128.0)         # an 8-GPU node with a 128-core quota
+    per, caps = b.lanes_per_rank(8, {"streams": 16, "pool_lanes": 24})
+    assert per == 16.0 and caps["streams"] == (16, 16) and caps["pool_lanes"] == (24, 16)
+
+
+def test_one_thread_cpu_figure_is_the_committed_measurement():
+    b = _bench_module()
+    d = b.committed_one_thread(64)
+    assert d and d["measured"] is True and 0.015 < d["value"] < 0.04 and "profiles/" in d["source"]
+    assert b.committed_one_thread(20) is None

@@ -670,6 +670,47 @@ def test_concurrent_proofs_on_shared_circuit_are_deterministic(gpu):
         assert by == wits[k][2], (lane, rep, k)
 
 
+def test_host_witness_entry_on_eight_lanes_equals_prove_device(gpu):
+    # the drop-in entry (plonk/prover.rs:145 -> gl_prove_columns): 64 proofs of the m = 64 circuit from HOST
+    # witness matrices -- 135 separate pageable vectors each, as MatrixWitness.wire_values holds them (iop/witness.rs:256-258) -- on 8
+    # lanes at once, each through the library's two-deep pinned H2D ring, byte-identical to gl_prove_device of the same witness; the
+    # chunked copy is also exercised with columns that straddle chunk boundaries (m = 20: 8 KiB columns, one chunk)
+    import threading
+    p, ctx = gpu
+    for m, count, nl in ((64, 64, 8), (20, 12, 4)):
+        hc = p.MatmulCircuit(m)
+        cd = hc.build(ctx)
+        wits = []
+        for k in range(4):
+            a, b = rand_field(900 + k, m * m) % (2**32 - 1), rand_field(950 + k, m * m) % (2**32 - 1)
+            wires, pis = hc.witness(a, b, filler_seed=70 + k)
+            dbuf = ctx.alloc(wires.nbytes).upload(wires)              # (kept alive across the call: the proof reads it)
+            want = cd.prove_device(dbuf.ptr, pis).to_bytes()
+            dbuf.free()
+            cols = p.api.HostColumns([wires[c].copy() for c in range(135)], hc.n)      # 135 separate allocations
+            wits.append((cols, pis, want, wires))
+        lanes = [(ctx, cd)] + [(lambda c: (c, p.api.CircuitView(cd, c)))(p.Context(device=0)) for _ in range(nl - 1)]
+        out, errors = [None] * count, []
+
+        def work(lane):
+            try:
+                for i in range(lane, count, nl):
+                    out[i] = lanes[lane][1].prove_columns(wits[i % 4][0], wits[i % 4][1]).to_bytes()
+                lanes[lane][0].synchronize()
+            except Exception as e:
+                errors.append(e)
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(nl)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert not errors, errors
+        for i in range(count):
+            assert out[i] == wits[i % 4][2], (m, i)
+        # the contiguous-matrix entry (gl_prove) goes through the same ring
+        assert cd.prove(wits[1][3], wits[1][1]).to_bytes() == wits[1][2]
+        ok, why = cd.verify(out[0])
+        assert ok, why
+
+
 def test_sixteen_proofs_in_flight_m64_soak(gpu):
     # bench.py's configuration: 16 contexts, the first of them the circuit's own, 16 host threads, m = 64 -- and, as tools/soak.py
     # does, every thread now and then verifies a proof, which reads the circuit's Merkle cap through the CIRCUIT's context while

@@ -25,6 +25,7 @@ cp $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/${R}_nt
 echo "[5] SQ counters: NTT and prove() kernels"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/sq_ntt -o s --output-format csv -- python3 $ROOT/tools/prof_ntt.py 64 2 > /dev/null 2>&1
 cp $(find $OUT/sq_ntt -name "*counter_collection.csv" | head -1) $OUT/${R}_ntt20_pmc_sq_counters.csv
+python3 $ROOT/tools/ntt_valu_report.py $OUT/${R}_ntt20_pmc_sq_counters.csv 64 $OUT/ntt20_valu.json > /dev/null
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/sq_prove -o s --output-format csv -- python3 $ROOT/tools/prove_profile.py 64 2 > $OUT/${R}_prove_m64_scopes.txt 2>&1
 cp $(find $OUT/sq_prove -name "*counter_collection.csv" | head -1) $OUT/${R}_prove_m64_pmc_sq_counters.csv
 # the per-proof instruction count of the THROUGHPUT configuration (what bench.py's 16 proofs in flight run): the profile proves one
@@ -36,7 +37,21 @@ python3 $ROOT/tools/valu_report.py $(find $OUT/sq_prove2t -name "*counter_collec
 unset GL_COOP_MAX_NODES GL_POW_WINDOW_LOG
 echo "[6] NTT ablation (memory-only time of the passes)"
 cd $ROOT && bash tools/ablation.sh > $OUT/${R}_ntt_ablation.txt 2>&1
-echo "[7] m = 128 (config 5)"
+echo "[7] m = 128 (config 5): scopes, kernel stats, HBM traffic per kernel (separate passes)"
 python3 $ROOT/tools/prove_profile.py 128 3 > $OUT/${R}_prove_m128_scopes.txt 2>&1
-rm -rf $OUT/kt_prove $OUT/kt_ntt $OUT/pmc_fetch $OUT/pmc_write $OUT/sq_ntt $OUT/sq_prove $OUT/sq_prove2t $OUT/sq_prove8
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/kt_m128 -o kt --output-format csv -- python3 $ROOT/tools/prove_profile.py 128 3 > /dev/null 2>&1
+cp $OUT/kt_m128/kt_kernel_stats.csv $OUT/${R}_prove_m128_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch128 -o f --output-format csv -- python3 $ROOT/tools/prove_profile.py 128 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write128 -o w --output-format csv -- python3 $ROOT/tools/prove_profile.py 128 1 > /dev/null 2>&1
+cp $(find $OUT/pmc_fetch128 -name "*counter_collection.csv" | head -1) $OUT/${R}_m128_pmc_FETCH_SIZE.csv
+cp $(find $OUT/pmc_write128 -name "*counter_collection.csv" | head -1) $OUT/${R}_m128_pmc_WRITE_SIZE.csv
+CORR=$(python3 -c "import json; print(json.load(open('$OUT/ntt20_traffic.json'))['calibration']['read_correction'])")
+python3 $ROOT/tools/kernel_traffic_report.py $OUT/${R}_prove_m128_kernel_stats.csv $OUT/${R}_m128_pmc_FETCH_SIZE.csv $OUT/${R}_m128_pmc_WRITE_SIZE.csv $CORR $OUT/${R}_m128_traffic.json > $OUT/${R}_m128_traffic.md
+echo "[8] primitives: edge-grid check + cycle counts, SGPR hazard probe, clock probe"
+cd $ROOT
+tools/ubench/bin/gl_prims > $OUT/${R}_gl_primitives.txt 2>&1 || echo "gl_prims FAILED" >> $OUT/${R}_gl_primitives.txt
+tools/ubench/bin/sgpr_hazard > $OUT/${R}_sgpr_hazard_probe.txt 2>&1
+tools/ubench/bin/clock_probe > $OUT/${R}_clock_probe.txt 2>&1
+rm -rf $OUT/kt_prove $OUT/kt_ntt $OUT/pmc_fetch $OUT/pmc_write $OUT/sq_ntt $OUT/sq_prove $OUT/sq_prove2t $OUT/sq_prove8 $OUT/kt_m128 $OUT/pmc_fetch128 $OUT/pmc_write128
 ls -la $OUT
