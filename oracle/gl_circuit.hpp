@@ -64,8 +64,9 @@ struct CircuitData {
     std::vector<Target> a_targets, b_targets, public_inputs;
     std::vector<ArithOp> arith_ops;                     // in generator (creation) order
     std::vector<size_t> poseidon_rows;
-    size_t pi_row = 0, constant_row = 0;
-    std::vector<std::pair<size_t, u64>> constant_wires; // (wire column on constant_row, value)
+    size_t pi_row = 0;
+    struct ConstantWire { size_t row, wire; u64 value; };
+    std::vector<ConstantWire> constant_wires;           // ConstantGenerator outputs: (row, wire column, value), one ConstantGate per two constants
     size_t target_index(const Target& t) const {        // iop/target.rs: wires first, then virtual targets
         return t.is_wire ? t.row * common.config.num_wires + t.col : common.degree() * common.config.num_wires + t.index;
     }
@@ -86,6 +87,8 @@ struct CircuitBuilder {
     std::vector<ConstGen> constant_generators;
     std::vector<ArithOp> arith_ops;
     std::vector<size_t> poseidon_rows;
+    typedef std::tuple<bool, size_t, size_t, size_t> TargetKey;
+    std::map<std::tuple<u64, u64, TargetKey, TargetKey, TargetKey>, Target> arithmetic_results;
 
     Target add_virtual_target() { return Target::virt(virtual_target_index++); }
     size_t add_gate(GateType t, u64 c0 = 0, u64 c1 = 0) {        // circuit_builder.rs:353-388
@@ -130,6 +133,11 @@ struct CircuitBuilder {
             if (k0 && canon(mul(v0, c0)) == 1) return m1;
             if (k1 && canon(mul(v1, c0)) == 1) return m0;
         }
+        // base_arithmetic_results (arithmetic.rs:64-75): the same operation on the same targets is not placed twice
+        auto tkey = [](const Target& t) { return std::make_tuple(t.is_wire, t.row, t.col, t.index); };
+        auto memo_key = std::make_tuple(canon(c0), canon(c1), tkey(m0), tkey(m1), tkey(addend));
+        auto hit = arithmetic_results.find(memo_key);
+        if (hit != arithmetic_results.end()) return hit->second;
         // find_slot(ArithmeticGate, params = constants = [c0, c1])  (circuit_builder.rs:665-695)
         auto key = std::make_pair(c0, c1);
         size_t row, slot;
@@ -141,10 +149,13 @@ struct CircuitBuilder {
         connect(m1, Target::wire(row, 4 * slot + 1));
         connect(addend, Target::wire(row, 4 * slot + 2));
         arith_ops.push_back({row, slot, c0, c1});
+        arithmetic_results[memo_key] = Target::wire(row, 4 * slot + 3);
         return Target::wire(row, 4 * slot + 3);
     }
     Target mul_t(Target x, Target y) { return arithmetic(1, 0, x, y, x); }                 // arithmetic.rs:210-213
     Target add_t(Target x, Target y) { Target o = one(); return arithmetic(1, 1, x, o, y); }   // :187-191
+    Target mul_const(u64 c, Target x) { Target ct = constant(c); return mul_t(ct, x); }      // :169-172
+    Target add_const(Target x, u64 c) { Target ct = constant(c); return add_t(x, ct); }      // :163-166
 
     // hash_n_to_hash_no_pad in circuit (hashing.rs:24-59) with PoseidonGate routing (poseidon.rs:724-751)
     std::array<Target, 4> hash_public_inputs(const std::vector<Target>& inputs) {
@@ -188,10 +199,8 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
             auto g = b.constant_generators[gi++];
             b.gate_instances[g.row].constants[g.constant_index] = kv.first;
             b.connect(Target::wire(g.row, g.wire_index), kv.second);
-            cd.constant_row = g.row;
-            cd.constant_wires.push_back({g.wire_index, kv.first});
+            cd.constant_wires.push_back({g.row, g.wire_index, kv.first});
         }
-        assert(gi <= 2 && "this restatement places one ConstantGate");
     }
     while (b.gate_instances.size() & (b.gate_instances.size() - 1)) b.add_gate(GATE_NOOP);   // blind_and_pad, zk off
     const size_t degree = b.gate_instances.size();
@@ -324,7 +333,8 @@ static inline CircuitData build_matmul_circuit(size_t m, unsigned threads = 1, b
     return cd;
 }
 
-// Two more circuits over the same gate set, to exercise circuit shapes the matmul family never produces (tests only):
+// More circuits over the same gate set (tests only): shapes the matmul family never produces, and the reference's own example
+// programs that use only these five gates (kinds 3-6: plonky2/examples/{fibonacci,factorial,easy_polynomial,square_root}.rs):
 //   kind 1 "hash only": `param` inputs, all registered as public inputs -> gates {Noop, Constant, PublicInput, Poseidon}
 //                       (no ArithmeticGate; selector groups {0,1,2} | {3})
 //   kind 2 "chain":     x0, x1 inputs, `param` steps x_{i+2} = x_{i+1} x_i + x_i, NO public inputs -> gates {Noop, Constant,
@@ -336,6 +346,36 @@ static inline CircuitData build_test_circuit(int kind, size_t param, unsigned th
     cd.m = 0;
     if (kind == 1) {
         for (size_t i = 0; i < param; i++) { Target t = b.add_virtual_target(); cd.a_targets.push_back(t); b.public_inputs.push_back(t); }
+    } else if (kind == 3) {
+        // plonky2/examples/fibonacci.rs:21-36: `param` (99) additions from (initial_a, initial_b); public inputs a, b, result
+        Target ia = b.add_virtual_target(), ib = b.add_virtual_target();
+        Target prev = ia, cur = ib;
+        for (size_t i = 0; i < param; i++) { Target t = b.add_t(prev, cur); prev = cur; cur = t; }
+        b.public_inputs = {ia, ib, cur};
+        cd.a_targets = {ia, ib};
+    } else if (kind == 4) {
+        // plonky2/examples/factorial.rs:22-33: cur = initial * 2 * 3 * ... * param (100); public inputs initial, result
+        Target initial = b.add_virtual_target(), cur = initial;
+        for (size_t i = 2; i <= param; i++) { Target it = b.constant((u64)i); cur = b.mul_t(cur, it); }
+        b.public_inputs = {initial, cur};
+        cd.a_targets = {initial};
+    } else if (kind == 5) {
+        // plonky2/examples/easy_polynomial.rs:19-28: x^2 - 4 x + 7; public inputs x, result
+        Target x = b.add_virtual_target();
+        Target a = b.mul_t(x, x);
+        Target bb = b.mul_const(4, x);
+        Target c = b.mul_const(GL_P - 1, bb);
+        Target d = b.add_t(a, c);
+        Target e = b.add_const(d, 7);
+        b.public_inputs = {x, e};
+        cd.a_targets = {x};
+    } else if (kind == 6) {
+        // plonky2/examples/square_root.rs:104-107: x_squared = square(x) is the public input; the example's SquareRootGenerator finds
+        // x from x_squared outside the circuit -- at the witness-matrix boundary x is simply given
+        Target x = b.add_virtual_target();
+        Target x2 = b.mul_t(x, x);                          // square(x) = mul(x, x) (arithmetic.rs:199-201)
+        b.public_inputs = {x2};
+        cd.a_targets = {x};
     } else {
         Target x0 = b.add_virtual_target(), x1 = b.add_virtual_target();
         cd.a_targets = {x0, x1};
@@ -404,7 +444,7 @@ static inline Witness generate_witness(const CircuitData& cd, const std::vector<
     assert(a.size() == cd.a_targets.size() && b.size() == cd.b_targets.size());
     for (size_t i = 0; i < a.size(); i++) put(cd.a_targets[i], a[i]);
     for (size_t i = 0; i < b.size(); i++) put(cd.b_targets[i], b[i]);
-    for (auto& cw : cd.constant_wires) put(Target::wire(cd.constant_row, cw.first), cw.second);
+    for (auto& cw : cd.constant_wires) put(Target::wire(cw.row, cw.wire), cw.value);
     for (auto& op : cd.arith_ops) {                      // ArithmeticBaseGenerator (arithmetic_base.rs:203-218)
         u64 m0 = get(Target::wire(op.row, 4 * op.slot)), m1 = get(Target::wire(op.row, 4 * op.slot + 1)), ad = get(Target::wire(op.row, 4 * op.slot + 2));
         put(Target::wire(op.row, 4 * op.slot + 3), add(mul(mul(m0, m1), op.c0), mul(ad, op.c1)));

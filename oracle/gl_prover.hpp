@@ -16,6 +16,28 @@
 
 namespace orc {
 
+// ReducingFactor::reduce_polys_base (util/reducing.rs:83-94): sum_j alpha^j * poly_j with FORWARD powers alpha^0, alpha^1, ...
+static inline std::vector<Ext2> reduce_polys_base(Ext2 alpha, const std::vector<const std::vector<u64>*>& polys, size_t n) {
+    std::vector<Ext2> comp(n, Ext2{0, 0});
+    Ext2 ap = ext(1);
+    for (auto* p : polys) { for (size_t i = 0; i < n && i < p->size(); i++) comp[i] = eadd(comp[i], escalar(ap, (*p)[i])); ap = emul(ap, alpha); }
+    return comp;
+}
+// ReducingFactor::reduce (util/reducing.rs:36-42): Horner from the back, sum_j alpha^j * v_j
+static inline Ext2 reduce_ext(Ext2 alpha, const std::vector<Ext2>& vals) {
+    Ext2 acc{0, 0};
+    for (size_t i = vals.size(); i-- > 0;) acc = eadd(emul(acc, alpha), vals[i]);
+    return acc;
+}
+// PolynomialCoeffs::divide_by_linear (field/src/polynomial/division.rs:75-88): (p(X) - p(z)) / (X - z), len - 1 coefficients
+static inline std::vector<Ext2> divide_by_linear(const std::vector<Ext2>& coeffs, Ext2 z) {
+    std::vector<Ext2> bs(coeffs.size());
+    Ext2 acc{0, 0};
+    for (size_t i = coeffs.size(); i-- > 0;) { acc = eadd(emul(acc, z), coeffs[i]); bs[i] = acc; }
+    return std::vector<Ext2>(bs.begin() + (bs.empty() ? 0 : 1), bs.end());
+}
+
+
 // ---- Challenger: duplex sponge, challenges pop from the END of the rate (challenger.rs:81-92,134-148) ----
 struct Challenger {
     PState state; std::vector<u64> in, out;
@@ -295,15 +317,8 @@ static inline bool prove(const CircuitData& cd, const Witness& w, unsigned threa
     Ext2 alpha = ch.ext_challenge();
     std::vector<Ext2> final_poly;                        // coefficient form
     auto reduce_and_divide = [&](const std::vector<const std::vector<u64>*>& polys, Ext2 point) {
-        std::vector<Ext2> comp(n, Ext2{0, 0});
-        Ext2 ap = ext(1);
-        for (auto* p : polys) { for (size_t i = 0; i < n; i++) comp[i] = eadd(comp[i], escalar(ap, (*p)[i])); ap = emul(ap, alpha); }
-        // divide_by_linear (division.rs:75-88)
-        std::vector<Ext2> bs(n);
-        Ext2 acc{0, 0};
-        for (size_t i = n; i-- > 0;) { acc = eadd(emul(acc, point), comp[i]); bs[i] = acc; }
-        std::vector<Ext2> q(bs.begin() + 1, bs.end());
-        q.push_back(Ext2{0, 0});
+        std::vector<Ext2> q = divide_by_linear(reduce_polys_base(alpha, polys, n), point);
+        q.push_back(Ext2{0, 0});                          // oracle.rs:188-190: "+ 0" keeps the length a power of two
         return q;
     };
     {

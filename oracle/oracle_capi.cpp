@@ -201,6 +201,32 @@ size_t orc_check_partial_products(const u64* num, const u64* den, size_t n, cons
     for (size_t i = 0; i < res.size(); i++) out[i] = canon(res[i]);
     return res.size();
 }
+// ---- stand-alone pieces of prove_openings, for the reference's own property tests (util/reducing.rs, polynomial/division.rs, cosets.rs)
+// out[2 n]: sum_j alpha^j polys[j] (polys: npolys x n base-field coefficients, row-major)
+void orc_reduce_polys_base(const u64* alpha2, const u64* polys, size_t npolys, size_t n, u64* out) {
+    std::vector<std::vector<u64>> ps(npolys);
+    std::vector<const std::vector<u64>*> ptr;
+    for (size_t j = 0; j < npolys; j++) { ps[j].assign(polys + j * n, polys + (j + 1) * n); ptr.push_back(&ps[j]); }
+    auto r = reduce_polys_base(Ext2{alpha2[0], alpha2[1]}, ptr, n);
+    for (size_t i = 0; i < n; i++) { out[2 * i] = canon(r[i].a); out[2 * i + 1] = canon(r[i].b); }
+}
+// out[2]: ReducingFactor::reduce of n extension values
+void orc_reduce_ext(const u64* alpha2, const u64* vals, size_t n, u64* out2) {
+    std::vector<Ext2> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = Ext2{vals[2 * i], vals[2 * i + 1]};
+    Ext2 r = reduce_ext(Ext2{alpha2[0], alpha2[1]}, v);
+    out2[0] = canon(r.a); out2[1] = canon(r.b);
+}
+// out[2 (n - 1)]: (p(X) - p(z)) / (X - z) for n extension coefficients
+void orc_divide_by_linear(const u64* coeffs, size_t n, const u64* z2, u64* out) {
+    std::vector<Ext2> c(n);
+    for (size_t i = 0; i < n; i++) c[i] = Ext2{coeffs[2 * i], coeffs[2 * i + 1]};
+    auto q = divide_by_linear(c, Ext2{z2[0], z2[1]});
+    for (size_t i = 0; i < q.size(); i++) { out[2 * i] = canon(q[i].a); out[2 * i + 1] = canon(q[i].b); }
+}
+// get_unique_coset_shifts (field/src/cosets.rs:9-24): g^0 .. g^(num - 1), g = MULTIPLICATIVE_GROUP_GENERATOR (the k_is of build())
+void orc_unique_coset_shifts(size_t num, u64* out) { u64 x = 1; for (size_t i = 0; i < num; i++) { out[i] = canon(x); x = mul(x, GL_GENERATOR); } }
+
 void* orc_circuit_new(size_t m, unsigned threads) { return new CircuitData(build_matmul_circuit(m, threads)); }
 // CommonCircuitData only (what verify() needs besides the cap and the digest): cheap even for m = 128
 void* orc_circuit_new_verifier_only(size_t m) { return new CircuitData(build_matmul_circuit(m, 1, false)); }
@@ -286,12 +312,12 @@ size_t orc_circuit_data_bytes(const void* c, int kind, uint8_t* out, size_t cap)
 }
 void orc_circuit_free(void* c) { delete (CircuitData*)c; }
 // out: [degree_bits, num_constants, num_gate_constraints, num_partial_products, num_public_inputs, num_selectors,
-//       num_fri_rounds, final_poly_len, pi_row, constant_row, num_arith_ops, num_poseidon_rows]
+//       num_fri_rounds, final_poly_len, pi_row, constant_row (the first ConstantGate), num_arith_ops, num_poseidon_rows]
 void orc_circuit_info(const void* c, u64* out) {
     const CircuitData* cd = (const CircuitData*)c;
     const CommonData& cm = cd->common;
     u64 v[12] = {cm.degree_bits, cm.num_constants, cm.num_gate_constraints, cm.num_partial_products, cm.num_public_inputs,
-                 cm.selectors.num_selectors(), cm.fri_reduction_arity_bits.size(), cm.final_poly_len(), cd->pi_row, cd->constant_row,
+                 cm.selectors.num_selectors(), cm.fri_reduction_arity_bits.size(), cm.final_poly_len(), cd->pi_row, cd->constant_wires.empty() ? 0 : cd->constant_wires[0].row,
                  cd->arith_ops.size(), cd->poseidon_rows.size()};
     memcpy(out, v, sizeof v);
 }

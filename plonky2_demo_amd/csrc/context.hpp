@@ -150,6 +150,13 @@ struct gl_ctx {
     int get_offsets_table(const uint64_t* host, size_t len, const uint64_t** d_out);
 };
 
+// RAII scope of the optional per-launch timing
+struct GlTimed {
+    gl_ctx* c;
+    GlTimed(gl_ctx* ctx, const char* name) : c(ctx) { c->timing_begin(name); }
+    ~GlTimed() { c->timing_end(); }
+};
+
 // ---- NTT launcher (ntt.hip) ---------------------------------------------------------------------------
 // dst[b][k] = post_const * post_shift^k * sum_i (pre_shift^i * src[b][i]) * w^(+-ik),  i < n_in, k < 2^lgN
 // pre_shift / post_shift == 0 mean "no scaling".  src may equal dst.  Output canonical.

@@ -34,6 +34,10 @@ struct Reader {
     uint8_t u8() { return (uint8_t)take(1); }
     uint32_t u32() { return (uint32_t)take(4); }
     uint64_t u64() { return take(8); }
+    // a `usize` that this library keeps in 32 bits: anything larger is a file this library cannot represent, never a narrowing
+    // (2^32 + 135 must not read as 135)
+    uint32_t usize32() { const uint64_t v = take(8); if (v > 0xFFFFFFFFull) { ok = false; wide = true; return 0; } return (uint32_t)v; }
+    bool wide = false;
 };
 
 uint32_t gate_tag(uint8_t type) {
@@ -47,12 +51,15 @@ void write_fri_config(Writer& w, const gl_circuit_desc& d) {          // mod.rs:
     w.u8(1); w.u64(STD_ARITY_BITS); w.u64(STD_FINAL_POLY_BITS);       // FriReductionStrategy::ConstantArityBits(4, 5) (mod.rs:1609-1615)
 }
 int read_fri_config(Reader& r, gl_circuit_desc& d) {
-    d.rate_bits = (uint32_t)r.u64(); d.cap_height = (uint32_t)r.u64(); d.num_query_rounds = (uint32_t)r.u64(); d.proof_of_work_bits = r.u32();
+    d.rate_bits = r.usize32(); d.cap_height = r.usize32(); d.num_query_rounds = r.usize32(); d.proof_of_work_bits = r.u32();
     const uint8_t strat = r.u8();
-    if (strat == 0) { const uint64_t k = r.u64(); for (uint64_t i = 0; i < k && r.ok; i++) (void)r.u64(); }
-    else if (strat == 1) { (void)r.u64(); (void)r.u64(); }
-    else if (strat == 2) { if (r.u8()) (void)r.u64(); }
-    else return GL_ERR_ARG;
+    // the reduction strategy is not part of gl_circuit_desc (the rounds themselves are): only the one this library writes back
+    // is accepted, so that bytes -> desc -> bytes cannot silently change a field
+    if (strat == 1) {
+        const uint64_t arity = r.u64(), final_bits = r.u64();
+        GL_REQUIRE(!r.ok || (arity == STD_ARITY_BITS && final_bits == STD_FINAL_POLY_BITS), GL_ERR_UNSUPPORTED, "FRI reduction strategy other than ConstantArityBits(4, 5)");
+    } else if (strat == 0 || strat == 2) return gl_fail(GL_ERR_UNSUPPORTED, "FRI reduction strategy other than ConstantArityBits(4, 5)", __FILE__, __LINE__);
+    else return gl_fail(GL_ERR_ARG, "unknown FRI reduction strategy", __FILE__, __LINE__);
     return GL_OK;
 }
 }   // namespace
@@ -62,6 +69,10 @@ extern "C" int gl_common_data_to_bytes(const gl_circuit_desc* desc, uint8_t* h_o
     GL_REQUIRE(desc && num_bytes, GL_ERR_ARG, "gl_common_data_to_bytes: null argument");
     const gl_circuit_desc& d = *desc;
     GL_REQUIRE(d.num_gates >= 1 && d.num_gates <= 8 && d.num_fri_rounds <= 8 && d.num_selectors >= 1 && d.num_selectors <= 4, GL_ERR_ARG, "bad circuit description");
+    // everything the writer indexes or divides by (k_is holds 80 entries)
+    GL_REQUIRE(d.num_routed_wires >= 4 && d.num_routed_wires <= 80 && d.quotient_degree_factor >= 1 && d.num_constants >= d.num_selectors, GL_ERR_ARG,
+               "bad circuit description: routed wires 4..80, quotient degree factor >= 1, constants >= selectors");
+    for (uint32_t g = 0; g < d.num_gates; g++) GL_REQUIRE(d.gate_types[g] <= 4, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon}");
     Writer w;
     // CircuitConfig (mod.rs:1662-1686)
     w.u64(d.num_wires); w.u64(d.num_routed_wires); w.u64(STD_CONFIG_NUM_CONSTANTS); w.u64(STD_SECURITY_BITS); w.u64(d.num_challenges);
@@ -106,11 +117,11 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
     Reader r(h_bytes, num_bytes);
     gl_circuit_desc d;
     memset(&d, 0, sizeof d);
-    d.num_wires = (uint32_t)r.u64(); d.num_routed_wires = (uint32_t)r.u64();
-    const uint64_t cfg_consts = r.u64(); (void)r.u64() /* security_bits */;
-    d.num_challenges = (uint32_t)r.u64();
+    d.num_wires = r.usize32(); d.num_routed_wires = r.usize32();
+    const uint64_t cfg_consts = r.u64(), security_bits = r.u64();
+    d.num_challenges = r.usize32();
     const uint64_t max_qdf = r.u64();
-    (void)r.u8();                                       // use_base_arithmetic_gate
+    const uint8_t base_arith = r.u8();                  // use_base_arithmetic_gate
     const uint8_t zk = r.u8();
     GL_TRY(read_fri_config(r, d));                      // config.fri_config
     gl_circuit_desc fp = d;
@@ -118,11 +129,14 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
     const uint64_t nred = r.u64();
     GL_REQUIRE(r.ok && nred <= 8, GL_ERR_UNSUPPORTED, "more than 8 FRI reduction rounds");
     d.num_fri_rounds = (uint32_t)nred;
-    for (uint64_t i = 0; i < nred; i++) d.fri_arity_bits[i] = (uint32_t)r.u64();
-    d.degree_bits = (uint32_t)r.u64();
+    for (uint64_t i = 0; i < nred; i++) d.fri_arity_bits[i] = r.usize32();
+    d.degree_bits = r.usize32();
     const uint8_t hiding = r.u8();
+    GL_REQUIRE(!r.wide, GL_ERR_UNSUPPORTED, "a size field of CommonCircuitData exceeds 32 bits");
     GL_REQUIRE(r.ok, GL_ERR_ARG, "truncated CommonCircuitData");
     GL_REQUIRE(!zk && !hiding, GL_ERR_UNSUPPORTED, "zero-knowledge circuits are not supported");
+    // fields gl_circuit_desc does not carry are written back as standard_recursion_config's: anything else is refused, not dropped
+    GL_REQUIRE(security_bits == STD_SECURITY_BITS && base_arith == 1, GL_ERR_UNSUPPORTED, "security_bits / use_base_arithmetic_gate differ from standard_recursion_config");
     GL_REQUIRE(fp.rate_bits == d.rate_bits && fp.cap_height == d.cap_height && fp.num_query_rounds == d.num_query_rounds && fp.proof_of_work_bits == d.proof_of_work_bits,
                GL_ERR_ARG, "fri_params.config differs from config.fri_config");
     const uint64_t ngates = r.u64();
@@ -140,24 +154,25 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
     }
     const uint64_t nsel = r.u64();
     GL_REQUIRE(r.ok && nsel == ngates, GL_ERR_ARG, "selector_indices length differs from the number of gates");
-    for (uint64_t g = 0; g < ngates; g++) d.gate_selector_index[g] = (uint32_t)r.u64();
+    for (uint64_t g = 0; g < ngates; g++) d.gate_selector_index[g] = r.usize32();
     const uint64_t ngroups = r.u64();
     GL_REQUIRE(r.ok && ngroups >= 1 && ngroups <= 4, GL_ERR_UNSUPPORTED, "1..4 selector groups");
     d.num_selectors = (uint32_t)ngroups;
     for (uint64_t k = 0; k < ngroups; k++) {
-        const uint32_t start = (uint32_t)r.u64(), end = (uint32_t)r.u64();
+        const uint32_t start = r.usize32(), end = r.usize32();
         GL_REQUIRE(r.ok && start < end && end <= ngates, GL_ERR_ARG, "bad selector group");
         for (uint32_t g = start; g < end; g++) { d.gate_group_start[g] = start; d.gate_group_end[g] = end; }
     }
-    d.quotient_degree_factor = (uint32_t)r.u64();
+    d.quotient_degree_factor = r.usize32();
     (void)r.u64();                                      // num_gate_constraints: implied by the gate list
-    d.num_constants = (uint32_t)r.u64();
-    d.num_public_inputs = (uint32_t)r.u64();
+    d.num_constants = r.usize32();
+    d.num_public_inputs = r.usize32();
     const uint64_t nk = r.u64();
     GL_REQUIRE(r.ok && nk == d.num_routed_wires && nk <= 80, GL_ERR_UNSUPPORTED, "k_is: one coset shift per routed wire, at most 80");
     for (uint64_t j = 0; j < nk; j++) d.k_is[j] = r.u64();
     (void)r.u64();                                      // num_partial_products: implied
     const uint64_t nlp = r.u64(), nls = r.u64(), nluts = r.u64();
+    GL_REQUIRE(!r.wide, GL_ERR_UNSUPPORTED, "a size field of CommonCircuitData exceeds 32 bits");
     GL_REQUIRE(r.ok, GL_ERR_ARG, "truncated CommonCircuitData");
     GL_REQUIRE(nlp == 0 && nls == 0 && nluts == 0, GL_ERR_UNSUPPORTED, "lookup arguments are not supported");
     GL_REQUIRE(max_qdf == d.quotient_degree_factor && cfg_consts + d.num_selectors == d.num_constants, GL_ERR_UNSUPPORTED, "constants / quotient degree layout");

@@ -88,6 +88,31 @@ class Oracle:
         self.lib.orc_evaluate_naive(_p(c), _sz(c.size), _p(out))
         return out
 
+    # ---- stand-alone pieces of prove_openings (util/reducing.rs, polynomial/division.rs, cosets.rs)
+    def reduce_polys_base(self, alpha, polys):
+        """sum_j alpha^j polys[j]: alpha = (a0, a1), polys [npolys][n] base-field coefficients -> [n][2]."""
+        ps = np.ascontiguousarray(u64(polys))
+        out = np.empty((ps.shape[1], 2), dtype=np.uint64)
+        self.lib.orc_reduce_polys_base(_p(u64(alpha)), _p(ps), _sz(ps.shape[0]), _sz(ps.shape[1]), _p(out))
+        return out
+
+    def reduce_ext(self, alpha, vals):
+        v = np.ascontiguousarray(u64(vals)).reshape(-1, 2)
+        out = np.empty(2, dtype=np.uint64)
+        self.lib.orc_reduce_ext(_p(u64(alpha)), _p(v), _sz(v.shape[0]), _p(out))
+        return out
+
+    def divide_by_linear(self, coeffs, z):
+        c = np.ascontiguousarray(u64(coeffs)).reshape(-1, 2)
+        out = np.empty((max(c.shape[0] - 1, 0), 2), dtype=np.uint64)
+        self.lib.orc_divide_by_linear(_p(c), _sz(c.shape[0]), _p(u64(z)), _p(out))
+        return out
+
+    def unique_coset_shifts(self, num):
+        out = np.empty(num, dtype=np.uint64)
+        self.lib.orc_unique_coset_shifts(_sz(num), _p(out))
+        return out
+
     # ---- hashing
     def poseidon(self, states, naive=False):
         s = u64(states).copy()

@@ -1,0 +1,31 @@
+"""The library context's host code (plonky2_demo_amd/csrc/context.hip: pinned staging buffers, stream-ordered pool, reference
+counting, the copy entry points) under ThreadSanitizer, over a stub HIP runtime whose streams are worker threads (tools/sanitizer/).
+CPU only.  VERDICT round 2, item 7: the one data corruption of that round was a host-side race in this code that 117 GPU tests missed."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = os.path.join(ROOT, "tools", "sanitizer")
+ENV = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
+
+
+def _run(target, *args):
+    subprocess.check_call(["make", "-s", "-C", SAN, target], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return subprocess.run([os.path.join(SAN, target)] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=ENV)
+
+
+def test_sixteen_lanes_with_cross_context_cap_reads_are_race_free():
+    # bench.py's / tools/soak.py's pattern: 16 threads proving on their own contexts, every 7th iteration reading the shared circuit's
+    # cap through the CIRCUIT's context, handles outliving gl_ctx_destroy
+    for lanes, iters in ((16, 80), (3, 200)):
+        r = _run("ctx_race", lanes, iters)
+        assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+        assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+        assert "0 wrong copies or failed calls" in r.stdout
+
+
+def test_the_harness_sees_round_twos_single_staging_buffer_bug():
+    # the same pattern with ONE pinned staging buffer per context (round 2's first version): a data race report and wrong bytes
+    r = _run("ctx_race_single_buffer", 16, 80)
+    assert "ThreadSanitizer: data race" in r.stderr
+    assert r.returncode != 0 and "0 wrong copies" not in r.stdout

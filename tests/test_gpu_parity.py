@@ -811,6 +811,10 @@ def test_generic_circuits_over_the_same_gate_set(gpu, orc, kind, param):
     oc = orc.circuit_of_kind(kind, param, threads=8)
     a = rand_field(100 * kind + param, param if kind == 1 else 2)
     w = oc.witness(a, np.zeros(0, dtype=np.uint64), filler_seed=kind)
+    _prove_generic_and_compare(p, oc, w)
+
+
+def _prove_generic_and_compare(p, oc, w):
     op = w.prove(threads=8)
     cd = p.GenericCircuitData(oc.product_desc(), oc.constants_sigmas())
     assert (cd.circuit_digest == oc.digest).all() and (cd.constants_sigmas_cap == oc.constants_sigmas_cap).all()
@@ -819,6 +823,36 @@ def test_generic_circuits_over_the_same_gate_set(gpu, orc, kind, param):
     assert gp.to_bytes() == op.to_bytes()
     assert cd.verify(gp) == (True, "")
     assert oc.verify_bytes(gp.to_bytes(), cd.constants_sigmas_cap, cd.circuit_digest)[0]
+    return gp
+
+
+@pytest.mark.parametrize("name,kind,param,inputs,outputs", [
+    ("fibonacci", 3, 99, [0, 1], [0, 1, 3736710860384812976]),        # examples/fibonacci.rs:22-42 (the README's printed value)
+    ("fibonacci from (5, 8)", 3, 99, [5, 8], None),
+    ("factorial", 4, 100, [1], [1, 3822706312645553057]),              # examples/factorial.rs:22-36
+    ("easy polynomial", 5, 0, [1], [1, 4]),                            # examples/easy_polynomial.rs:19-31: x^2 - 4x + 7 at 1
+    ("easy polynomial at p - 3", 5, 0, [P - 3], [P - 3, 28]),
+    ("square root", 6, 0, [1234567890123456789], [1234567890123456789 ** 2 % P]),     # examples/square_root.rs:104-107
+])
+def test_reference_example_circuits(gpu, orc, name, kind, param, inputs, outputs):
+    # the reference's own example programs that use only the five supported gates, built by the oracle's generic CircuitBuilder
+    # (several ConstantGates, the arithmetic memo table, 2-8 rows ... 64 rows), proved on the GPU: bytes equal the oracle's, both
+    # verifiers accept, and the public outputs are the ones the examples print
+    p, ctx = gpu
+    oc = orc.circuit_of_kind(kind, param, threads=8)
+    w = oc.witness(np.array(inputs, dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=17)
+    gp = _prove_generic_and_compare(p, oc, w)
+    got = [int(x) for x in w.public_inputs()]
+    if outputs is None:
+        a, b = inputs
+        for _ in range(param):
+            a, b = b, (a + b) % P
+        outputs = [inputs[0], inputs[1], b]
+    assert got == outputs, name
+    # the proof carries them (ProofWithPublicInputs: u64 count + values at the end of the bytes)
+    by = gp.to_bytes()
+    tail = np.frombuffer(by[-8 * len(outputs):], dtype=np.uint64)
+    assert [int(x) for x in tail] == outputs
 
 
 def test_prover_pool_matches_individual_proofs(gpu):

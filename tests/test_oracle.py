@@ -2,6 +2,7 @@
 
 These pin the CPU restatement before it is trusted as the checker of the HIP path."""
 import numpy as np
+import pytest
 
 from oracle_lib import P, rand_field, splitmix64
 
@@ -295,3 +296,108 @@ def test_poseidon_tables_equal_the_reference_tables():
     # textbook permutation by the generator itself and by the KATs on the device
     G = g.derive_groups(rc, T["M"])
     assert product["POSEIDON_G3_M3"] == flat(G["M3"]) and product["POSEIDON_G3_K"] == flat(G["K"])
+
+
+@pytest.mark.parametrize("kind,param,inputs,outputs", [
+    (3, 99, [0, 1], [0, 1, 3736710860384812976]),            # plonky2/examples/fibonacci.rs: the value its README prints
+    (4, 100, [1], [1, 3822706312645553057]),                 # plonky2/examples/factorial.rs
+    (5, 0, [1], [1, 4]),                                     # plonky2/examples/easy_polynomial.rs
+    (6, 0, [3], [9]),                                        # plonky2/examples/square_root.rs
+])
+def test_reference_example_circuits_on_the_oracle(orc, kind, param, inputs, outputs):
+    # the generic CircuitBuilder restatement (several ConstantGates, the base_arithmetic_results memo) on the reference's own
+    # example programs over the five supported gates: public outputs as the examples print them, proof accepted by the verifier
+    oc = orc.circuit_of_kind(kind, param, threads=4)
+    w = oc.witness(np.array(inputs, dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=3)
+    assert [int(x) for x in w.public_inputs()] == outputs
+    pr = w.prove(threads=4)
+    assert pr.verify()[0]
+    if kind == 3:
+        assert oc.info["num_arith_ops"] == 99 and oc.info["degree_bits"] == 3      # 5 ArithmeticGates + Poseidon + PI + Constant = 8 rows
+    if kind == 4:
+        assert oc.info["degree_bits"] == 6      # 99 constants + 0 -> 50 ConstantGates, 5 ArithmeticGates, Poseidon, PI -> 57 rows -> 64
+
+
+# ---- the reference's own property tests for the pieces of prove_openings, replayed against the oracle -------------------------
+def _ext_mul(x, y):                     # (a0 + a1 X)(b0 + b1 X) mod X^2 - 7 with Python integers
+    return ((x[0] * y[0] + 7 * x[1] * y[1]) % P, (x[0] * y[1] + x[1] * y[0]) % P)
+
+
+def _ext_add(x, y):
+    return ((x[0] + y[0]) % P, (x[1] + y[1]) % P)
+
+
+def test_division_by_linear_property(orc):
+    # field/src/polynomial/division.rs:145-158 (there over the quartic extension; the path uses the quadratic one):
+    # poly == quotient * (X - z) + poly(z) for random lengths, incl. length 1 (empty quotient)
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 17, 64, int(rng.integers(1, 1000))):
+        coeffs = rand_field(1000 + n, (n, 2))
+        z = tuple(int(v) for v in rand_field(2000 + n, 2))
+        q = [tuple(int(v) for v in row) for row in orc.divide_by_linear(coeffs, z)]
+        assert len(q) == n - 1
+        ev = (0, 0)
+        for c in reversed(coeffs):
+            ev = _ext_add(_ext_mul(ev, z), (int(c[0]), int(c[1])))
+        negz = ((P - z[0]) % P, (P - z[1]) % P)
+        back = [(0, 0)] * n
+        for i, qi in enumerate(q):                      # quotient * (X - z)
+            back[i] = _ext_add(back[i], _ext_mul(qi, negz))
+            back[i + 1] = _ext_add(back[i + 1], qi)
+        back[0] = _ext_add(back[0], ev)
+        assert back == [(int(c[0]), int(c[1])) for c in coeffs], n
+
+
+@pytest.mark.parametrize("n", [10, 11, 100])
+def test_reducing_factor_properties(orc, n):
+    # plonky2/src/util/reducing.rs:248-327 checks ReducingFactor::reduce against its in-circuit twin for n = 10, 11, 100 (the gadget's
+    # gates are off this path); the out-of-circuit half is replayed here against the definition: reduce(vs) = sum_j alpha^j v_j,
+    # reduce_polys_base = the same coefficient by coefficient with FORWARD powers (:83-94), and the shift by alpha^count (:96-106)
+    alpha = tuple(int(v) for v in rand_field(31 + n, 2))
+    vs = [(i, 0) for i in range(n)]                                    # test_reduce_gadget: FF::from_canonical_usize(0..n)
+    want, ap = (0, 0), (1, 0)
+    for v in vs:
+        want = _ext_add(want, _ext_mul(ap, v))
+        ap = _ext_mul(ap, alpha)
+    assert tuple(int(x) for x in orc.reduce_ext(alpha, np.array(vs, dtype=np.uint64))) == want
+    base = rand_field(77 + n, n)                                       # test_reduce_gadget_base: random base-field values
+    wantb, ap = (0, 0), (1, 0)
+    for v in base:
+        wantb = _ext_add(wantb, _ext_mul(ap, (int(v), 0)))
+        ap = _ext_mul(ap, alpha)
+    assert tuple(int(x) for x in orc.reduce_ext(alpha, np.stack([base, np.zeros(n, dtype=np.uint64)], axis=1))) == wantb
+    polys = rand_field(99 + n, (n, 8))
+    red = orc.reduce_polys_base(alpha, polys)
+    for i in range(8):
+        assert tuple(int(x) for x in red[i]) == tuple(int(x) for x in orc.reduce_ext(alpha, np.stack([polys[:, i], np.zeros(n, dtype=np.uint64)], axis=1)))
+    # after reducing n polynomials the factor's count is n: shifting by alpha^n then adding a second batch is the reduction of the
+    # concatenation read backwards -- the "final = alpha^2 Q0 + Q1" order of prove_openings (fri/oracle.rs:193-196)
+    two = rand_field(5 + n, (2, 8))
+    shift = (1, 0)
+    for _ in range(2):
+        shift = _ext_mul(shift, alpha)
+    red2 = orc.reduce_polys_base(alpha, two)
+    both = orc.reduce_polys_base(alpha, np.concatenate([two, polys]))
+    for i in range(8):
+        lhs = _ext_add(_ext_mul(tuple(int(x) for x in red[i]), shift), tuple(int(x) for x in red2[i]))
+        assert lhs == tuple(int(x) for x in both[i])
+
+
+def test_unique_coset_shifts_give_distinct_cosets(orc):
+    # field/src/cosets.rs:33-53: 50 shifts of the subgroup of order 2^5 -- the union of the cosets has no repeated element; and the
+    # circuit's k_is (circuit_builder.rs:1007) are the first 80 of them
+    shifts = [int(x) for x in orc.unique_coset_shifts(50)]
+    assert shifts[:3] == [1, 7, 49]
+    g = pow(7, (P - 1) >> 5, P)
+    seen = set()
+    for sh in shifts:
+        x = sh
+        for _ in range(32):
+            assert x not in seen, "duplicate element"
+            seen.add(x)
+            x = x * g % P
+    assert len(seen) == 50 * 32
+    oc = orc.circuit(2, threads=1)
+    k = np.zeros(80, dtype=np.uint64)
+    orc.lib.orc_circuit_k_is(oc.h, k.ctypes.data_as(__import__("ctypes").c_void_p))
+    assert [int(x) for x in k] == [int(x) for x in orc.unique_coset_shifts(80)]

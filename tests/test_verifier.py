@@ -182,3 +182,41 @@ def test_common_data_reader_rejects_what_the_library_cannot_prove(orc):
     for cut in (0, 7, 60, len(good) - 1):
         with pytest.raises(p.Plonky2Mi355xError):
             api.common_data_from_bytes(bytes(good[:cut]))
+    # size fields are never narrowed: num_wires = 2^32 + 135 is refused, not read as 135
+    bad = bytearray(good); bad[0:8] = (2**32 + 135).to_bytes(8, "little")
+    with pytest.raises(p.Plonky2Mi355xError) as e:
+        api.common_data_from_bytes(bytes(bad))
+    assert e.value.code == 3
+    # fields the description does not carry must equal what the writer emits: security_bits, use_base_arithmetic_gate, the strategy
+    bad = bytearray(good); bad[3 * 8:4 * 8] = (96).to_bytes(8, "little")           # security_bits
+    with pytest.raises(p.Plonky2Mi355xError) as e:
+        api.common_data_from_bytes(bytes(bad))
+    assert e.value.code == 3
+    bad = bytearray(good); bad[6 * 8] = 0                                          # use_base_arithmetic_gate = false
+    with pytest.raises(p.Plonky2Mi355xError):
+        api.common_data_from_bytes(bytes(bad))
+    strat = 6 * 8 + 2 + 3 * 8 + 4
+    assert good[strat] == 1
+    bad = bytearray(good); bad[strat + 1:strat + 9] = (3).to_bytes(8, "little")    # ConstantArityBits(3, 5)
+    with pytest.raises(p.Plonky2Mi355xError) as e:
+        api.common_data_from_bytes(bytes(bad))
+    assert e.value.code == 3
+
+
+def test_common_data_writer_validates_its_description():
+    # a public C entry point: an out-of-range description must come back as an error, not as an out-of-bounds read of k_is[80] or a
+    # division by zero
+    import copy
+    import plonky2_demo_amd as p
+    from plonky2_demo_amd import api
+    hc = p.MatmulCircuit(2)
+    for field, value in (("num_routed_wires", 81), ("num_routed_wires", 2**31), ("quotient_degree_factor", 0), ("num_constants", 1), ("num_gates", 9)):
+        d = copy.copy(hc.desc)
+        setattr(d, field, value)
+        with pytest.raises(p.Plonky2Mi355xError):
+            api.common_data_to_bytes(d)
+    d = copy.copy(hc.desc)
+    d.gate_types[0] = 7
+    with pytest.raises(p.Plonky2Mi355xError) as e:
+        api.common_data_to_bytes(d)
+    assert e.value.code == 3
