@@ -64,6 +64,8 @@ struct CircuitData {
     std::vector<Target> a_targets, b_targets, public_inputs;
     std::vector<ArithOp> arith_ops;                     // in generator (creation) order
     std::vector<size_t> poseidon_rows;
+    struct SplitRecipe { Target integer; std::vector<size_t> rows; };
+    std::vector<SplitRecipe> split_ops;                 // BaseSumGate rows: sums from the integer, limbs from the sums
     size_t pi_row = 0;
     struct ConstantWire { size_t row, wire; u64 value; };
     std::vector<ConstantWire> constant_wires;           // ConstantGenerator outputs: (row, wire column, value), one ConstantGate per two constants
@@ -156,6 +158,32 @@ struct CircuitBuilder {
     Target add_t(Target x, Target y) { Target o = one(); return arithmetic(1, 1, x, o, y); }   // :187-191
     Target mul_const(u64 c, Target x) { Target ct = constant(c); return mul_t(ct, x); }      // :169-172
     Target add_const(Target x, u64 c) { Target ct = constant(c); return add_t(x, ct); }      // :163-166
+
+    // split_le (gadgets/split_join.rs:19-63) / range_check (gadgets/range_check.rs:14-16): k BaseSumGate<2> rows of 63 limbs,
+    // unused bits tied to zero, the gates' sums recombined with mul_const_add(2^63, acc, sum) and tied to the integer
+    struct SplitOp { Target integer; std::vector<size_t> rows; };
+    std::vector<SplitOp> split_ops;                               // WireSplitGenerator + one BaseSplitGenerator per row
+    std::vector<Target> split_le(Target integer, size_t num_bits) {
+        std::vector<Target> bits;
+        if (num_bits == 0) return bits;
+        const size_t k = (num_bits + BASE_SUM_LIMBS - 1) / BASE_SUM_LIMBS;
+        std::vector<size_t> rows;
+        for (size_t i = 0; i < k; i++) rows.push_back(add_gate(GATE_BASE_SUM));
+        for (size_t row : rows) for (size_t c = 1; c <= BASE_SUM_LIMBS; c++) bits.push_back(Target::wire(row, c));
+        for (size_t i = num_bits; i < bits.size(); i++) connect(bits[i], zero());      // assert_zero (circuit_builder.rs)
+        bits.resize(num_bits);
+        Target z = zero(), acc = z;
+        const u64 base = u64(1) << BASE_SUM_LIMBS;                                     // F::TWO.exp_u64(num_limbs)
+        for (size_t i = rows.size(); i-- > 0;) {
+            Target sum = Target::wire(rows[i], 0);
+            Target bt = constant(base);
+            acc = arithmetic(1, 1, bt, acc, sum);                                      // mul_const_add(base, acc, sum) = mul_add(c, acc, sum)
+        }
+        connect(acc, integer);
+        split_ops.push_back({integer, rows});
+        return bits;
+    }
+    void range_check(Target x, size_t n_log) { (void)split_le(x, n_log); }
 
     // hash_n_to_hash_no_pad in circuit (hashing.rs:24-59) with PoseidonGate routing (poseidon.rs:724-751)
     std::array<Target, 4> hash_public_inputs(const std::vector<Target>& inputs) {
@@ -308,6 +336,7 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
     cd.public_inputs = b.public_inputs;
     cd.arith_ops = b.arith_ops;
     cd.poseidon_rows = b.poseidon_rows;
+    for (auto& so : b.split_ops) cd.split_ops.push_back({so.integer, so.rows});
     cd.pi_row = pi_row;
 }
 
@@ -369,6 +398,12 @@ static inline CircuitData build_test_circuit(int kind, size_t param, unsigned th
         Target e = b.add_const(d, 7);
         b.public_inputs = {x, e};
         cd.a_targets = {x};
+    } else if (kind == 7) {
+        // plonky2/examples/range_check.rs:20-24: the value is a public input and is range-checked to `param` (6) bits
+        Target value = b.add_virtual_target();
+        b.public_inputs = {value};
+        b.range_check(value, param);
+        cd.a_targets = {value};
     } else if (kind == 6) {
         // plonky2/examples/square_root.rs:104-107: x_squared = square(x) is the public input; the example's SquareRootGenerator finds
         // x from x_squared outside the circuit -- at the witness-matrix boundary x is simply given
@@ -445,19 +480,50 @@ static inline Witness generate_witness(const CircuitData& cd, const std::vector<
     for (size_t i = 0; i < a.size(); i++) put(cd.a_targets[i], a[i]);
     for (size_t i = 0; i < b.size(); i++) put(cd.b_targets[i], b[i]);
     for (auto& cw : cd.constant_wires) put(Target::wire(cw.row, cw.wire), cw.value);
-    for (auto& op : cd.arith_ops) {                      // ArithmeticBaseGenerator (arithmetic_base.rs:203-218)
-        u64 m0 = get(Target::wire(op.row, 4 * op.slot)), m1 = get(Target::wire(op.row, 4 * op.slot + 1)), ad = get(Target::wire(op.row, 4 * op.slot + 2));
-        put(Target::wire(op.row, 4 * op.slot + 3), add(mul(mul(m0, m1), op.c0), mul(ad, op.c1)));
-    }
+    // The reference runs every generator once its dependencies are known (iop/generator.rs:19-98): a fixed point over the three
+    // kinds of generator present here.  The order of generation cannot change a value.
+    auto is_set = [&](const Target& t) { return set[rep(t)] != 0; };
+    std::vector<char> arith_done(cd.arith_ops.size(), 0), split_done(cd.split_ops.size(), 0), pos_done(cd.poseidon_rows.size(), 0);
     std::vector<u64> rowbuf(135);
-    for (size_t row : cd.poseidon_rows) {
-        u64 in[12];
-        for (int i = 0; i < 12; i++) in[i] = get(Target::wire(row, PoseidonWires::INPUT + i));
-        u64 swap = get(Target::wire(row, PoseidonWires::SWAP));
-        poseidon_gate_witness(in, swap, rowbuf.data());
-        for (int c = PoseidonWires::DELTA; c < PoseidonWires::END; c++) put(Target::wire(row, c), rowbuf[c]);
-        for (int i = 0; i < 12; i++) put(Target::wire(row, PoseidonWires::OUTPUT + i), rowbuf[PoseidonWires::OUTPUT + i]);
+    for (bool progress = true; progress;) {
+        progress = false;
+        for (size_t k = 0; k < cd.arith_ops.size(); k++) {   // ArithmeticBaseGenerator (arithmetic_base.rs:203-218)
+            auto& op = cd.arith_ops[k];
+            Target t0 = Target::wire(op.row, 4 * op.slot), t1 = Target::wire(op.row, 4 * op.slot + 1), t2 = Target::wire(op.row, 4 * op.slot + 2);
+            if (arith_done[k] || !is_set(t0) || !is_set(t1) || !is_set(t2)) continue;
+            put(Target::wire(op.row, 4 * op.slot + 3), add(mul(mul(get(t0), get(t1)), op.c0), mul(get(t2), op.c1)));
+            arith_done[k] = 1; progress = true;
+        }
+        for (size_t k = 0; k < cd.split_ops.size(); k++) {   // WireSplitGenerator (split_join.rs:117-142), BaseSplitGenerator (base_sum.rs:183-207)
+            auto& so = cd.split_ops[k];
+            if (split_done[k] || !is_set(so.integer)) continue;
+            u64 v = canon(get(so.integer));
+            for (size_t row : so.rows) {
+                u64 t = v & ((u64(1) << BASE_SUM_LIMBS) - 1);
+                v >>= BASE_SUM_LIMBS;
+                put(Target::wire(row, 0), t);
+                for (size_t i = 0; i < BASE_SUM_LIMBS; i++) { put(Target::wire(row, 1 + i), t & 1); t >>= 1; }
+            }
+            assert(v == 0 && "Integer too large to fit in the BaseSumGates");
+            split_done[k] = 1; progress = true;
+        }
+        for (size_t k = 0; k < cd.poseidon_rows.size(); k++) {
+            const size_t row = cd.poseidon_rows[k];
+            if (pos_done[k]) continue;
+            bool ready = is_set(Target::wire(row, PoseidonWires::SWAP));
+            for (int i = 0; i < 12 && ready; i++) ready = is_set(Target::wire(row, PoseidonWires::INPUT + i));
+            if (!ready) continue;
+            u64 in[12];
+            for (int i = 0; i < 12; i++) in[i] = get(Target::wire(row, PoseidonWires::INPUT + i));
+            u64 swap = get(Target::wire(row, PoseidonWires::SWAP));
+            poseidon_gate_witness(in, swap, rowbuf.data());
+            for (int c = PoseidonWires::DELTA; c < PoseidonWires::END; c++) put(Target::wire(row, c), rowbuf[c]);
+            for (int i = 0; i < 12; i++) put(Target::wire(row, PoseidonWires::OUTPUT + i), rowbuf[PoseidonWires::OUTPUT + i]);
+            pos_done[k] = 1; progress = true;
+        }
     }
+    for (char d : arith_done) assert(d && "an arithmetic operation never became ready");
+    for (char d : pos_done) assert(d && "a PoseidonGate never became ready");
     { u64 st = filler_seed; for (size_t c = 4; c < nw; c++) put(Target::wire(cd.pi_row, c), splitmix64_next(st) % GL_P); }
     Witness w;
     w.wire_values.assign(nw, std::vector<u64>(degree, 0));

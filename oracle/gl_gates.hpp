@@ -28,12 +28,14 @@ template <> inline u64 kconst<u64>(u64 c) { return c; }
 template <> inline Ext2 kconst<Ext2>(u64 c) { return Ext2{c, 0}; }
 template <class K> static inline K ksbox(K x) { K x2 = kmul(x, x), x4 = kmul(x2, x2), x3 = kmul(x, x2); return kmul(x3, x4); }
 
-enum GateType { GATE_NOOP = 0, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON, GATE_NUM_TYPES };
+// (the numbering is the product's gl_circuit_desc.gate_types: 5 = BaseSumGate<2> with the 63 limbs of new_from_config)
+enum GateType { GATE_NOOP = 0, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON, GATE_BASE_SUM, GATE_NUM_TYPES };
+static const size_t BASE_SUM_LIMBS = 63;                 // gates/base_sum.rs:31-35: min(log_floor(p - 1, 2) = 63, num_routed_wires - 1 = 79)
 static const size_t UNUSED_SELECTOR = 0xFFFFFFFFull;     // selectors.rs:14
 
 static inline unsigned gate_degree(GateType g) {
     switch (g) { case GATE_NOOP: return 0; case GATE_CONSTANT: return 1; case GATE_PUBLIC_INPUT: return 1;
-                 case GATE_ARITHMETIC: return 3; default: return 7; }
+                 case GATE_ARITHMETIC: return 3; case GATE_BASE_SUM: return 2 /* base_sum.rs:139-141 */; default: return 7; }
 }
 static inline std::string gate_id(GateType g) {           // Gate::id(): the sort key next to the degree
     switch (g) {
@@ -41,12 +43,14 @@ static inline std::string gate_id(GateType g) {           // Gate::id(): the sor
         case GATE_CONSTANT: return "ConstantGate { num_consts: 2 }";
         case GATE_PUBLIC_INPUT: return "PublicInputGate";
         case GATE_ARITHMETIC: return "ArithmeticGate { num_ops: 20 }";
+        case GATE_BASE_SUM: return "BaseSumGate { num_limbs: 63 } + Base: 2";          // base_sum.rs:49-51
         default: return "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>";
     }
 }
 static inline size_t gate_num_constraints(GateType g) {
     switch (g) { case GATE_NOOP: return 0; case GATE_CONSTANT: return 2; case GATE_PUBLIC_INPUT: return 4;
-                 case GATE_ARITHMETIC: return 20; default: return 123; }   // poseidon.rs:403-409
+                 case GATE_ARITHMETIC: return 20; case GATE_BASE_SUM: return 1 + BASE_SUM_LIMBS /* base_sum.rs:144-146 */;
+                 default: return 123; }   // poseidon.rs:403-409
 }
 
 // PoseidonGate wire layout (gates/poseidon.rs:36-96)
@@ -105,6 +109,13 @@ static inline void eval_constant(const K* consts, const K* w, K* out) {         
 template <class K>
 static inline void eval_public_input(const u64* pi_hash, const K* w, K* out) {  // public_input.rs:44-49
     for (int i = 0; i < 4; i++) out[i] = ksub(w[i], kconst<K>(pi_hash[i]));
+}
+template <class K>
+static inline void eval_base_sum(const K* w, K* out) {                          // base_sum.rs:63-76 / 153-170, B = 2
+    K computed = kconst<K>(0);                                                  // reduce_with_powers(limbs, 2) (plonk_common.rs:116-128)
+    for (size_t i = BASE_SUM_LIMBS; i-- > 0;) computed = kadd(kadd(computed, computed), w[1 + i]);
+    out[0] = ksub(computed, w[0]);
+    for (size_t i = 0; i < BASE_SUM_LIMBS; i++) out[1 + i] = kmul(w[1 + i], ksub(w[1 + i], kconst<K>(1)));      // (limb - 0)(limb - 1)
 }
 template <class K>
 static inline void eval_poseidon(const K* w, K* out) {                          // poseidon.rs:113-191
@@ -182,6 +193,7 @@ static inline void evaluate_gate_constraints(const SelectorsInfo& si, size_t num
             case GATE_CONSTANT: eval_constant<K>(gc, wires, tmp); break;
             case GATE_PUBLIC_INPUT: eval_public_input<K>(pi_hash, wires, tmp); break;
             case GATE_ARITHMETIC: eval_arithmetic<K>(gc, wires, tmp); break;
+            case GATE_BASE_SUM: eval_base_sum<K>(wires, tmp); break;
             default: eval_poseidon<K>(wires, tmp); break;
         }
         for (size_t j = 0; j < nc; j++) out[j] = kadd(out[j], kmul(filter, tmp[j]));

@@ -285,6 +285,7 @@ static void sink_common(ByteSink& o, const CommonData& cm) {
             case GATE_CONSTANT: o.word32(3); o.usize(c.num_constants); break;
             case GATE_NOOP: o.word32(9); break;
             case GATE_POSEIDON: o.word32(11); break;
+            case GATE_BASE_SUM: o.word32(2); o.usize(BASE_SUM_LIMBS); break;              // BaseSumGate<2>: write_usize(num_limbs) (base_sum.rs:53-55)
             default: o.word32(12); break;                                                  // PublicInputGate
         }
     }

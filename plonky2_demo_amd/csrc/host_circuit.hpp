@@ -26,7 +26,8 @@ static const gl_t POW2_GEN = 1753635133440165772ULL;
 inline gl_t root_of_unity(unsigned lg) { gl_t r = POW2_GEN; for (unsigned i = lg; i < 32; i++) r = gl_sqr(r); return gl_canon(r); }
 
 // gate type codes shared with the device kernels (order = the reference's sort by (degree, id))
-enum { G_NOOP = 0, G_CONSTANT = 1, G_PUBLIC_INPUT = 2, G_ARITHMETIC = 3, G_POSEIDON = 4 };
+enum { G_NOOP = 0, G_CONSTANT = 1, G_PUBLIC_INPUT = 2, G_ARITHMETIC = 3, G_POSEIDON = 4, G_BASE_SUM = 5 };
+enum { BASE_SUM_LIMBS = 63 };      // BaseSumGate::<2>::new_from_config (gates/base_sum.rs:31-35): wire 0 = sum, wires 1..=63 = limbs
 static const uint64_t UNUSED_SELECTOR = 0xFFFFFFFFull;        // gates/selectors.rs:14
 
 // PoseidonGate wire layout (gates/poseidon.rs:36-96)

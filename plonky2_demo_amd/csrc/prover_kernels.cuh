@@ -361,6 +361,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
                 }
                 break;
             }
+            case 5: {   // BaseSumGate<2>, 63 limbs (gates/base_sum.rs:153-170): sum of limb_i 2^i - sum, then limb (limb - 1) per limb
+                gl_t computed = 0;                                   // reduce_with_powers(limbs, 2): Horner from the top limb
+#pragma unroll 1
+                for (int k = 63; k >= 1; k -= 3) {                   // wires 1..63 = limbs 0..62, three range checks per step
+                    const gl_t l2 = w[(size_t)k * N], l1 = w[(size_t)(k - 1) * N], l0 = w[(size_t)(k - 2) * N];
+                    computed = glx_add_cc(glx_add_cc(computed, computed), l2);
+                    computed = glx_add_cc(glx_add_cc(computed, computed), l1);
+                    computed = glx_add_cc(glx_add_cc(computed, computed), l0);
+                    gl_t r2, r1, r0;
+                    glx_mul3<true>(l2, glx_sub_cc(l2, 1), l1, glx_sub_cc(l1, 1), l0, glx_sub_cc(l0, 1), r2, r1, r0);
+                    acc.add(T0 + k, r2); acc.add(T0 + k - 1, r1); acc.add(T0 + k - 2, r0);
+                }
+                acc.add(T0, glx_sub_cc(computed, w[0]));
+                break;
+            }
             default: break;   // NoopGate
         }
         gl_t fs0, fs1, unused;

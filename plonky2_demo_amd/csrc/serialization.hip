@@ -8,7 +8,7 @@
 // unpinned"); what is checked is a round trip, a second independent writer in the test oracle, and that
 // gl_verify_bytes accepts proofs through data that went through the byte form.
 //
-// Only circuits this library can prove / verify are representable: the five gates of the demo, standard_recursion_config's
+// Only circuits this library can prove / verify are representable: the five gates of the demo + BaseSumGate<2>, standard_recursion_config's
 // shape (no lookups, no zero-knowledge); anything else is GL_ERR_UNSUPPORTED when reading.
 #include "context.hpp"
 #include <cstring>
@@ -16,7 +16,8 @@
 
 namespace {
 // position of each gate type in DefaultGateSerializer's list (gate_serialization.rs:89-107)
-const uint32_t TAG_ARITHMETIC = 0, TAG_CONSTANT = 3, TAG_NOOP = 9, TAG_POSEIDON = 11, TAG_PUBLIC_INPUT = 12;
+const uint32_t TAG_ARITHMETIC = 0, TAG_BASE_SUM_2 = 2, TAG_CONSTANT = 3, TAG_NOOP = 9, TAG_POSEIDON = 11, TAG_PUBLIC_INPUT = 12;
+const uint64_t BASE_SUM_LIMBS = 63;     // BaseSumGate::<2>::new_from_config under standard_recursion_config (gates/base_sum.rs:31-35)
 // standard_recursion_config (plonk/circuit_data.rs:72-90)
 const uint64_t STD_SECURITY_BITS = 100, STD_CONFIG_NUM_CONSTANTS = 2, STD_FINAL_POLY_BITS = 5, STD_ARITY_BITS = 4;
 
@@ -41,10 +42,10 @@ struct Reader {
 };
 
 uint32_t gate_tag(uint8_t type) {
-    switch (type) { case 0: return TAG_NOOP; case 1: return TAG_CONSTANT; case 2: return TAG_PUBLIC_INPUT; case 3: return TAG_ARITHMETIC; default: return TAG_POSEIDON; }
+    switch (type) { case 0: return TAG_NOOP; case 1: return TAG_CONSTANT; case 2: return TAG_PUBLIC_INPUT; case 3: return TAG_ARITHMETIC; case 5: return TAG_BASE_SUM_2; default: return TAG_POSEIDON; }
 }
 uint64_t gate_constraints(uint8_t type, const gl_circuit_desc& d) {
-    switch (type) { case 0: return 0; case 1: return d.num_constants - d.num_selectors; case 2: return 4; case 3: return d.num_routed_wires / 4; default: return 123; }   // gates/poseidon.rs:403-409
+    switch (type) { case 0: return 0; case 1: return d.num_constants - d.num_selectors; case 2: return 4; case 3: return d.num_routed_wires / 4; case 5: return 1 + BASE_SUM_LIMBS /* gates/base_sum.rs:144-146 */; default: return 123; }   // gates/poseidon.rs:403-409
 }
 void write_fri_config(Writer& w, const gl_circuit_desc& d) {          // mod.rs:1628-1644
     w.u64(d.rate_bits); w.u64(d.cap_height); w.u64(d.num_query_rounds); w.u32(d.proof_of_work_bits);
@@ -72,7 +73,7 @@ extern "C" int gl_common_data_to_bytes(const gl_circuit_desc* desc, uint8_t* h_o
     // everything the writer indexes or divides by (k_is holds 80 entries)
     GL_REQUIRE(d.num_routed_wires >= 4 && d.num_routed_wires <= 80 && d.quotient_degree_factor >= 1 && d.num_constants >= d.num_selectors, GL_ERR_ARG,
                "bad circuit description: routed wires 4..80, quotient degree factor >= 1, constants >= selectors");
-    for (uint32_t g = 0; g < d.num_gates; g++) GL_REQUIRE(d.gate_types[g] <= 4, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon}");
+    for (uint32_t g = 0; g < d.num_gates; g++) GL_REQUIRE(d.gate_types[g] <= 5, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>}");
     Writer w;
     // CircuitConfig (mod.rs:1662-1686)
     w.u64(d.num_wires); w.u64(d.num_routed_wires); w.u64(STD_CONFIG_NUM_CONSTANTS); w.u64(STD_SECURITY_BITS); w.u64(d.num_challenges);
@@ -89,6 +90,7 @@ extern "C" int gl_common_data_to_bytes(const gl_circuit_desc* desc, uint8_t* h_o
         w.u32(gate_tag(d.gate_types[g]));
         if (d.gate_types[g] == 3) w.u64(d.num_routed_wires / 4);                   // ArithmeticGate { num_ops }
         if (d.gate_types[g] == 1) w.u64(d.num_constants - d.num_selectors);        // ConstantGate { num_consts }
+        if (d.gate_types[g] == 5) w.u64(BASE_SUM_LIMBS);                           // BaseSumGate<2> { num_limbs } (gates/base_sum.rs:53-55)
         const uint64_t c = gate_constraints(d.gate_types[g], d);
         if (c > max_constraints) max_constraints = c;
     }
@@ -150,7 +152,12 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
         else if (tag == TAG_PUBLIC_INPUT) d.gate_types[g] = 2;
         else if (tag == TAG_ARITHMETIC) { d.gate_types[g] = 3; arith_ops = r.u64(); }
         else if (tag == TAG_POSEIDON) d.gate_types[g] = 4;
-        else return gl_fail(GL_ERR_UNSUPPORTED, "gate outside {Noop, Constant, PublicInput, Arithmetic, Poseidon}", __FILE__, __LINE__);
+        else if (tag == TAG_BASE_SUM_2) {
+            d.gate_types[g] = 5;
+            const uint64_t limbs = r.u64();
+            GL_REQUIRE(!r.ok || limbs == BASE_SUM_LIMBS, GL_ERR_UNSUPPORTED, "BaseSumGate<2> with a limb count other than new_from_config's 63");
+        }
+        else return gl_fail(GL_ERR_UNSUPPORTED, "gate outside {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>}", __FILE__, __LINE__);
     }
     const uint64_t nsel = r.u64();
     GL_REQUIRE(r.ok && nsel == ngates, GL_ERR_ARG, "selector_indices length differs from the number of gates");

@@ -148,7 +148,7 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
                d.degree_bits >= 1 && d.degree_bits + d.rate_bits <= 32 && d.cap_height <= d.degree_bits + d.rate_bits && d.num_query_rounds >= 1,
                GL_ERR_ARG, "gl_verify: bad circuit description");
     for (unsigned g = 0; g < d.num_gates; g++)
-        GL_REQUIRE(d.gate_types[g] <= 4 && d.gate_selector_index[g] < d.num_selectors && d.gate_group_start[g] <= g && g < d.gate_group_end[g] && d.gate_group_end[g] <= d.num_gates,
+        GL_REQUIRE(d.gate_types[g] <= glhost::G_BASE_SUM && d.gate_selector_index[g] < d.num_selectors && d.gate_group_start[g] <= g && g < d.gate_group_end[g] && d.gate_group_end[g] <= d.num_gates,
                    GL_ERR_ARG, "gl_verify: bad gate / selector description");
     const size_t nch = 2, R = 80, W = 135, QF = 8, NPP = 9;            // partial products per challenge: ceil(80 / 8) - 1
     const size_t ncap = size_t(1) << d.cap_height, ncs = d.num_constants + R;
@@ -249,6 +249,14 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
                 case glhost::G_ARITHMETIC: cnt = 20;                                                                                                    // arithmetic_base.rs:72-92
                     for (int i = 0; i < 20; i++) tmp[i] = e_sub(wires[4 * i + 3], e_add(e_mul(e_mul(wires[4 * i], wires[4 * i + 1]), gate_consts[0]), e_mul(wires[4 * i + 2], gate_consts[1])));
                     break;
+                case glhost::G_BASE_SUM: {                                                                                                              // base_sum.rs:63-76, B = 2
+                    cnt = 1 + glhost::BASE_SUM_LIMBS;
+                    E computed = e_of(0);                                                                                                                // reduce_with_powers(limbs, 2)
+                    for (int i = glhost::BASE_SUM_LIMBS; i-- > 0;) computed = e_add(e_add(computed, computed), wires[1 + i]);
+                    tmp[0] = e_sub(computed, wires[0]);
+                    for (int i = 0; i < glhost::BASE_SUM_LIMBS; i++) tmp[1 + i] = e_mul(wires[1 + i], e_sub(wires[1 + i], e_of(1)));
+                    break;
+                }
                 default: cnt = 123; poseidon_gate_constraints(wires.data(), tmp); break;
             }
             for (size_t j = 0; j < cnt; j++) gate_terms[j] = e_add(gate_terms[j], e_mul(filter, tmp[j]));

@@ -855,6 +855,33 @@ def test_reference_example_circuits(gpu, orc, name, kind, param, inputs, outputs
     assert [int(x) for x in tail] == outputs
 
 
+@pytest.mark.parametrize("bits,value", [(6, 42), (6, 63), (1, 1), (63, 2**63 - 1), (64, 2**63 + 12345), (70, P - 1), (126, 99)])
+def test_range_check_circuits_with_base_sum_gate(gpu, orc, bits, value):
+    # the first gate outside the demo's five: BaseSumGate<2> (gates/base_sum.rs; 63 limbs from new_from_config), as used by
+    # plonky2/examples/range_check.rs:20-24 (value = 42, log_max = 6) -> split_le (gadgets/split_join.rs:19-63): one or two gate rows,
+    # unused limbs tied to zero, two rows recombined through an ArithmeticGate.  GPU proof bytes == oracle's, both verifiers accept,
+    # the circuit data survives the byte form (gate tag 2 + num_limbs).  PARITY UNPINNED against a Rust proof, as every proof here.
+    p, ctx = gpu
+    from plonky2_demo_amd import api
+    oc = orc.circuit_of_kind(7, bits, threads=8)
+    w = oc.witness(np.array([value], dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=bits)
+    gp = _prove_generic_and_compare(p, oc, w)
+    assert [int(x) for x in w.public_inputs()] == [value]
+    desc = oc.product_desc()
+    assert 5 in list(desc.gate_types)[:desc.num_gates]
+    common = api.common_data_to_bytes(desc)
+    assert common == oc.data_bytes(0)
+    d2, used = api.common_data_from_bytes(common)
+    assert used == len(common) and bytes(d2) == bytes(desc)
+    cd = p.GenericCircuitData(desc, oc.constants_sigmas())
+    vd = api.verifier_data_to_bytes(desc, cd.constants_sigmas_cap, cd.circuit_digest)
+    assert api.verify_bytes(vd, gp.to_bytes()) == (True, "")
+    # a proof whose range-checked value does not fit is not producible: flipping one limb opening makes both verifiers reject
+    bad = bytearray(gp.to_bytes())
+    bad[3 * 16 * 32 + (4 + 80) * 16 + 8 * 16] ^= 1           # an opened wire value (caps 3 x 16 x 32 B, then constants + sigmas, then wires)
+    assert not cd.verify(bytes(bad))[0] and not oc.verify_bytes(bytes(bad), cd.constants_sigmas_cap, cd.circuit_digest)[0]
+
+
 def test_prover_pool_matches_individual_proofs(gpu):
     # gl_prover_pool_*: one call, several proofs in flight on C++ threads (witness generation in HBM + prove per lane); every
     # proof equals the one produced alone on the default context, whatever lane and order it ran in

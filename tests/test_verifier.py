@@ -220,3 +220,42 @@ def test_common_data_writer_validates_its_description():
     with pytest.raises(p.Plonky2Mi355xError) as e:
         api.common_data_to_bytes(d)
     assert e.value.code == 3
+
+
+@pytest.mark.parametrize("bits,value", [(6, 42), (70, 2**64 - 2**32 - 5)])
+def test_base_sum_gate_circuits_verify_natively_and_through_the_byte_form(orc, bits, value):
+    # BaseSumGate<2> (gate type 5): gl_verify accepts the oracle's range_check proofs (plonky2/examples/range_check.rs), rejects tampered
+    # ones with the oracle's verdict, and the circuit data round-trips through the reference's byte form (gate tag 2, usize num_limbs)
+    import plonky2_demo_amd as p
+    from plonky2_demo_amd import api
+    oc = orc.circuit_of_kind(7, bits, threads=4)
+    w = oc.witness(np.array([value], dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=1)
+    proof = w.prove(threads=4).to_bytes()
+    desc = oc.product_desc()
+    assert list(desc.gate_types)[:desc.num_gates].count(5) == 1
+    cap, dig = np.ascontiguousarray(oc.constants_sigmas_cap), np.ascontiguousarray(oc.digest)
+    import ctypes
+    from plonky2_demo_amd._lib import lib, GL_OK
+    vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+
+    def native(by):
+        buf = np.frombuffer(by, dtype=np.uint8)
+        return lib.gl_verify(ctypes.byref(desc), vp(cap), vp(dig), vp(buf), buf.size) == GL_OK
+    assert native(proof), lib.gl_last_error()
+    common = api.common_data_to_bytes(desc)
+    assert common == oc.data_bytes(0)
+    d2, used = api.common_data_from_bytes(common)
+    assert used == len(common) and bytes(d2) == bytes(desc)
+    vd = api.verifier_data_to_bytes(desc, cap, dig)
+    assert vd == oc.data_bytes(1) and api.verify_bytes(vd, proof) == (True, "")
+    rng = np.random.default_rng(bits)
+    for _ in range(40):
+        bad = bytearray(proof)
+        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        assert native(bytes(bad)) == oc.verify_bytes(bytes(bad), cap, dig)[0]
+    # a different limb count is not representable
+    i = common.index((2).to_bytes(4, "little") + (63).to_bytes(8, "little"))
+    bad = bytearray(common); bad[i + 4:i + 12] = (32).to_bytes(8, "little")
+    with pytest.raises(p.Plonky2Mi355xError) as e:
+        api.common_data_from_bytes(bytes(bad))
+    assert e.value.code == 3
