@@ -26,13 +26,20 @@ clock, then the cap gather; value = 512 / t.  At N = 1 the default run reports i
 The same JSON line carries
   roofline:        BASELINE configs[1], the HBM-bound kernel family of the path: forward 2^20-point NTT over 64 polynomials,
                    algorithmic bytes 16*L*B (one 8-B read + one 8-B write per element) over the device time of
-                   its launches (HIP events on the launch stream);
+                   its launches (HIP events on the launch stream); valu_frac = the same launches against the VALU issue roof
+                   (instructions per element from the committed SQ_INSTS_VALU pass), at the nominal and at the measured clock;
   roofline_prove:  the headline kernel family: Poseidon permutations per second of the proofs against the measured
                    one-state-per-lane ceiling of the same chip, and the 2.0 GB of algorithmic bytes per proof against HBM;
   ntt:             GF elements/s of forward+inverse 2^20 NTTs (the second half of BASELINE.json's metric);
   extra:           BASELINE.md section 3's other rows (NTT at batch 1 / 16 / 256, LDE 2^17 -> 2^20 x 135, Merkle commit 2^18 x 135);
-  cpu_baseline:    the CPU restatement of the reference prover (oracle/, kind "port") on the host cores: all cores (median of 3
-                   proofs) and 1 thread (derived from a bounded sample, see its "sample" text).
+  with_host_witness: the same 16 lanes through gl_prove_columns from HOST witness matrices (135 pageable vectors, 35 MB of H2D per
+                   proof inside the clock): the PCIe-inclusive rate of the drop-in entry, never `value`;
+                   `--config4 --host-witness` is BASELINE configs[3] in that form ("incl. H2D of witnesses", SURVEY 8d);
+  host:            lanes per GPU (capped by min(affinity mask, cgroup CPU quota) / ranks), GPU_MAX_HW_QUEUES, host CPU seconds;
+  cpu_baseline:    the CPU restatement of the reference prover (oracle/, kind "port") on the host cores: all cores (median of 5
+                   proofs after a warm-up); `one_thread` quotes the committed measurement of one full 1-thread proof (45 s);
+  vs_baseline:     value / cpu_baseline.value -- the ratio to that CPU PORT (BASELINE.md publishes no number for this metric).
+The last proof of every lane of the timed loop is verified after the clock stops (config.lanes_verified_after_the_clock).
 """
 import argparse
 import ctypes
@@ -268,6 +275,12 @@ def ntt_leg(torch, ctx, lib, check, dev, batch, with_rows=True):
             per_elem = vi["valu_instructions_per_element"]["col"] + vi["valu_instructions_per_element"]["row"]
             peak = 256 * 4 * VALU_CLOCK_HZ / 4.0
             roofline["valu_frac"] = per_elem * batch * L / 64.0 / peak / (fwd_ms * 1e-3)
+            if "clock_GHz" in vi:
+                # at the clock the SQ counters show for these kernels (SQ_BUSY_CYCLES / duration, ~2.0 GHz under load, not the nominal 2.4)
+                clk = 0.5 * (vi["clock_GHz"]["col"] + vi["clock_GHz"]["row"]) * 1e9
+                roofline["valu_frac_at_measured_clock"] = per_elem * batch * L / 64.0 / (256 * 4 * clk / 4.0) / (fwd_ms * 1e-3)
+                roofline["measured_clock_GHz"] = clk / 1e9
+                roofline["valu_utilisation_from_counters"] = vi["valu_utilisation_at_that_clock"]
             roofline["valu"] = {"instructions_per_element": per_elem, "peak_wave_instructions_per_s": peak,
                                 "source": "profiles/ntt20_valu.json: SQ_INSTS_VALU of tools/prof_ntt.py (committed profile, not measured in this run); "
                                           "peak = 1024 SIMDs x %.1f GHz / 4 cycles per wave64 instruction" % (VALU_CLOCK_HZ / 1e9)}

@@ -294,8 +294,8 @@ __device__ __forceinline__ void ntt_lds_stages(gl_t* lds, const gl_t* __restrict
 // consecutive lanes take consecutive points of one column (the row pass: rows are contiguous).  The outputs land at their
 // Stockham positions; the caller synchronises (workgroup barrier: the twiddle table, and with CROSS the columns, were written by
 // other waves) and continues with ntt_lds_stages<LOGL, first radix>.
-template <int LOGL, bool INV, bool ZP, bool CROSS, class LOAD, class FIX>
-__device__ __forceinline__ void ntt_first_stage_direct(gl_t* lds, int tid, LOAD load, FIX fix) {
+template <int LOGL, bool INV, bool ZP, bool CROSS, class LOAD, class FIX, class MID>
+__device__ __forceinline__ void ntt_first_stage_direct(gl_t* lds, int tid, LOAD load, FIX fix, MID while_loading) {
     using G = NttGeom<LOGL>;
     static_assert(G::WAVE_OWNED, "direct first stage: wave-owned tiles only");
     constexpr int LOGR = ntt_first_radix(LOGL);
@@ -322,6 +322,7 @@ __device__ __forceinline__ void ntt_first_stage_direct(gl_t* lds, int tid, LOAD 
 #pragma unroll
         for (int r = 0; r < RIN; r++) u[q][r] = load(tcol[q], tj[q] + (r << LOGJ));     // every request goes out before the first use
     }
+    while_loading();                // work that does not need the inputs, placed under their memory latency
 #pragma unroll
     for (int q = 0; q < TPT; q++) {
 #pragma unroll
@@ -391,7 +392,8 @@ __device__ __forceinline__ void ntt_col_tile(const NttPassParams& p, gl_t* lds, 
                 const uint32_t i = ((uint32_t)i1 << lgN2) + c0 + (uint32_t)t;
                 if (pre_lo && i < n_in) return glx_mul<true>(v, ntt_pow2level(pre_lo, pre_hi, i));
                 return glx_canon(v);                  // the caller's values may be any u64 representatives
-            });
+            },
+            [] {});
         __syncthreads();
         ntt_lds_stages<LOGL, ntt_first_radix(LOGL), INV, ZP>(lds, p.tw_local, tid);
     } else {
@@ -489,11 +491,14 @@ __device__ __forceinline__ void ntt_row_tile(const NttPassParams& p, gl_t* lds, 
     if constexpr (G::WAVE_OWNED && !SINGLE && !NTT_ABLATION_BUILD) {
         // second pass over wave-owned rows: every wave reads its own rows (contiguous, canonical: the column pass wrote them)
         // straight into the registers of the first radix stage
+        // The twiddle table is requested first and its barrier sits UNDER the latency of the row loads (memory returns in order: the
+        // table words are there long before the rows): after it the waves of the workgroup run independently up to the final transpose.
         ntt_fill_lds_twiddles<LOGL>(lds, p.tw_local, tid);
         ntt_first_stage_direct<LOGL, INV, false, false>(lds, tid,
             [&](int t, int i2) -> gl_t { return ntt_ld(src, ((r0 + (uint32_t)t) << LOGL) + (uint32_t)i2); },
-            [](int, int, gl_t v) -> gl_t { return v; });
-        __syncthreads();
+            [](int, int, gl_t v) -> gl_t { return v; },
+            [] { __syncthreads(); });
+        ntt_wave_sync();
         ntt_lds_stages<LOGL, ntt_first_radix(LOGL), INV>(lds, p.tw_local, tid);
     } else {
     // load: e -> (r = e / L, i2 = e % L): contiguous rows
