@@ -83,7 +83,16 @@ typedef struct gl_circuit_desc {
     uint32_t gate_selector_index[8];
     uint32_t gate_group_start[8], gate_group_end[8];
     uint64_t k_is[80];                 /* coset shifts 7^j (field/src/cosets.rs:9-24)               */
+    /* ---- lookup argument (ONE lookup table; all zero without lookups).  Gate types 6 = LookupGate (40 slots), 7 = LookupTableGate
+     * (26 slots) (gates/lookup.rs, gates/lookup_table.rs); `num_constants` counts the lookup selector columns, which sit between the
+     * gate selectors and the gates' constants (circuit_builder.rs:991-1004) ---- */
+    uint32_t num_lookup_polys;         /* per challenge: 1 RE + ceil(40 / 7) partial SLDC = 7 (circuit_builder.rs:1079-1085)     */
+    uint32_t num_lookup_selectors;     /* TransSre, TransLdc, InitSre, LastLdc + one end selector per table = 5                */
+    uint32_t last_lu_row, last_lut_row, first_lut_row;   /* LookupWire (circuit_builder.rs:73-85): the gate rows are upside down */
+    uint32_t lut_len;                  /* entries of the table, <= GL_MAX_LUT_ENTRIES                                          */
+    uint16_t lut[2 * 1024];            /* (input, output) pairs (gates/lookup_table.rs:22)                                     */
 } gl_circuit_desc;
+#define GL_MAX_LUT_ENTRIES 1024
 
 /* ---- context ------------------------------------------------------------------------------------ */
 /* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL to let

@@ -43,6 +43,9 @@ struct CommonData {
     SelectorsInfo selectors;
     size_t num_gate_constraints = 0, num_constants = 0, num_public_inputs = 0, num_partial_products = 0;
     size_t quotient_degree_factor = 8;
+    size_t num_lookup_polys = 0, num_lookup_selectors = 0;      // circuit_data.rs:376-381: per challenge 1 RE + ceil(40 / 7) partial SLDC polynomials
+    size_t last_lut_row = 0;                                    // LookupTableGate's third field (lookup_table.rs:31-32): the first LookupTableGate row
+    std::vector<std::vector<std::pair<uint16_t, uint16_t>>> luts;   // the lookup tables: (input, output) pairs
     std::vector<u64> k_is;
     std::vector<unsigned> fri_reduction_arity_bits;
     size_t degree() const { return size_t(1) << degree_bits; }
@@ -64,6 +67,11 @@ struct CircuitData {
     std::vector<Target> a_targets, b_targets, public_inputs;
     std::vector<ArithOp> arith_ops;                     // in generator (creation) order
     std::vector<size_t> poseidon_rows;
+    struct LookupWire { size_t last_lu_gate, last_lut_gate, first_lut_gate; };      // circuit_builder.rs:73-85 (the gate rows are upside down)
+    std::vector<LookupWire> lookup_rows;
+    std::vector<std::vector<std::pair<Target, Target>>> lut_to_lookups;             // per table: (looking_in, looking_out) targets
+    struct LookupSlot { size_t row, slot, lut; };
+    std::vector<LookupSlot> lookup_slots;
     struct SplitRecipe { Target integer; std::vector<size_t> rows; };
     std::vector<SplitRecipe> split_ops;                 // BaseSumGate rows: sums from the integer, limbs from the sums
     size_t pi_row = 0;
@@ -159,6 +167,54 @@ struct CircuitBuilder {
     Target mul_const(u64 c, Target x) { Target ct = constant(c); return mul_t(ct, x); }      // :169-172
     Target add_const(Target x, u64 c) { Target ct = constant(c); return add_t(x, ct); }      // :163-166
 
+    // ---- lookups (gadgets/lookup.rs:56-125, circuit_builder.rs:222-252,609-660) ----
+    std::vector<std::vector<std::pair<uint16_t, uint16_t>>> luts;
+    std::vector<std::vector<std::pair<Target, Target>>> lut_to_lookups;
+    struct LookupWire { size_t last_lu_gate, last_lut_gate, first_lut_gate; };
+    std::vector<LookupWire> lookup_rows;
+    struct LookupSlot { size_t row, slot, lut; };
+    std::vector<LookupSlot> lookup_slots;                                        // one LookupGenerator each (lookup.rs:105-118)
+    std::map<std::pair<int, u64>, std::pair<size_t, size_t>> gate_slots;      // find_slot: (gate type, parameter) -> (row, next slot)
+    size_t add_lookup_table_from_pairs(const std::vector<std::pair<uint16_t, uint16_t>>& table) {
+        for (size_t i = 0; i < luts.size(); i++) if (luts[i] == table) return i;      // is_stored
+        luts.push_back(table); lut_to_lookups.emplace_back();
+        return luts.size() - 1;
+    }
+    Target add_lookup_from_index(Target looking_in, size_t lut_index) {
+        assert(lut_index < luts.size());
+        Target looking_out = add_virtual_target();
+        lut_to_lookups[lut_index].push_back({looking_in, looking_out});
+        return looking_out;
+    }
+    std::pair<size_t, size_t> find_slot(GateType t, u64 param, size_t num_ops) {  // circuit_builder.rs:665-695 (no constants for these gates)
+        auto key = std::make_pair((int)t, param);
+        auto it = gate_slots.find(key);
+        size_t row, slot;
+        if (it != gate_slots.end()) { row = it->second.first; slot = it->second.second; }
+        else { row = add_gate(t); slot = 0; }
+        if (slot == num_ops - 1) gate_slots.erase(key); else gate_slots[key] = {row, slot + 1};
+        return {row, slot};
+    }
+    void add_all_lookups() {                                                      // gadgets/lookup.rs:79-125
+        assert(luts.size() <= 1 && "this restatement places ONE lookup table (the gate order of several depends on their Debug strings)");
+        for (size_t li = 0; li < luts.size(); li++) {
+            assert(!lut_to_lookups[li].empty() && "LUT is unused");
+            const size_t last_lu_gate = gate_instances.size();
+            for (auto& lk : lut_to_lookups[li]) {
+                auto rs = find_slot(GATE_LOOKUP, (u64)li, LOOKUP_SLOTS);
+                lookup_slots.push_back({rs.first, rs.second, li});
+                connect(Target::wire(rs.first, 2 * rs.second), lk.first);
+                connect(Target::wire(rs.first, 2 * rs.second + 1), lk.second);
+            }
+            const size_t last_lut_gate = gate_instances.size();
+            const size_t num_lut_rows = (luts[li].size() - 1) / LOOKUP_TABLE_SLOTS + 1;
+            for (size_t c = 0; c < LOOKUP_TABLE_SLOTS * num_lut_rows; c++) (void)find_slot(GATE_LOOKUP_TABLE, 0, LOOKUP_TABLE_SLOTS);
+            const size_t first_lut_gate = gate_instances.size() - 1;
+            add_gate(GATE_NOOP);          // the row after the table is all zeros: initial constraints become a zero check
+            lookup_rows.push_back({last_lu_gate, last_lut_gate, first_lut_gate});
+        }
+    }
+
     // split_le (gadgets/split_join.rs:19-63) / range_check (gadgets/range_check.rs:14-16): k BaseSumGate<2> rows of 63 limbs,
     // unused bits tied to zero, the gates' sums recombined with mul_const_add(2^63, acc, sum) and tied to the integer
     struct SplitOp { Target integer; std::vector<size_t> rows; };
@@ -220,6 +276,7 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
     auto pi_hash = b.hash_public_inputs(b.public_inputs);
     size_t pi_row = b.add_gate(GATE_PUBLIC_INPUT);
     for (size_t i = 0; i < 4; i++) b.connect(pi_hash[i], Target::wire(pi_row, i));
+    b.add_all_lookups();                                        // circuit_builder.rs:938-939: LUT-related gates come right after the PI gate
     while (b.constants_to_targets.size() > b.constant_generators.size()) b.add_gate(GATE_CONSTANT);
     {
         size_t gi = 0;
@@ -268,6 +325,24 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
     for (size_t j = 0; j < degree; j++) {
         size_t i = si.gate_index(b.gate_instances[j].type), gr = si.selector_indices[i];
         for (size_t g = 0; g < si.groups.size(); g++) constant_vecs[g][j] = (si.groups.size() == 1 || g == gr) ? i : UNUSED_SELECTOR;
+    }
+    // lookup selectors (circuit_builder.rs:991-1002; gates/selectors.rs:50-103): TransSre, TransLdc, InitSre, LastLdc, then one "end"
+    // selector per table, between the gate selectors and the gates' constants
+    if (!b.luts.empty()) {
+        std::vector<std::vector<u64>> ls(LU_SEL_START_END + b.lookup_rows.size(), std::vector<u64>(degree, 0));
+        for (size_t t = 0; t < b.lookup_rows.size(); t++) {
+            auto& lr = b.lookup_rows[t];
+            for (size_t row = lr.last_lut_gate; row <= lr.first_lut_gate; row++) ls[LU_SEL_TRANS_SRE][row] = 1;
+            for (size_t row = lr.last_lu_gate; row < lr.last_lut_gate; row++) ls[LU_SEL_TRANS_LDC][row] = 1;
+            ls[LU_SEL_INIT_SRE][lr.first_lut_gate + 1] = 1;
+            ls[LU_SEL_LAST_LDC][lr.last_lu_gate] = 1;
+            ls[LU_SEL_START_END + t][lr.last_lut_gate] = 1;
+        }
+        cm.num_lookup_selectors = si.num_lookup_selectors = ls.size();
+        for (auto& v : ls) constant_vecs.push_back(v);
+        cm.num_lookup_polys = (LOOKUP_SLOTS + (cfg.max_quotient_degree_factor - 1) - 1) / (cfg.max_quotient_degree_factor - 1) + 1;     // :1079-1085
+        cm.luts = b.luts;
+        cm.last_lut_row = b.lookup_rows[0].last_lut_gate;
     }
     // constant_polys (:822-843): max_constants over gate types used
     size_t max_constants = 0;
@@ -337,6 +412,9 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
     cd.arith_ops = b.arith_ops;
     cd.poseidon_rows = b.poseidon_rows;
     for (auto& so : b.split_ops) cd.split_ops.push_back({so.integer, so.rows});
+    for (auto& lr : b.lookup_rows) cd.lookup_rows.push_back({lr.last_lu_gate, lr.last_lut_gate, lr.first_lut_gate});
+    cd.lut_to_lookups = b.lut_to_lookups;
+    for (auto& ls : b.lookup_slots) cd.lookup_slots.push_back({ls.row, ls.slot, ls.lut});
     cd.pi_row = pi_row;
 }
 
@@ -398,6 +476,20 @@ static inline CircuitData build_test_circuit(int kind, size_t param, unsigned th
         Target e = b.add_const(d, 7);
         b.public_inputs = {x, e};
         cd.a_targets = {x};
+    } else if (kind == 8 || kind == 9) {
+        // plonky2/src/lookup_test.rs:45-103 (test_one_lookup) / :276-362 (test_many_lookups): `param` inputs, each looked up in ONE table;
+        // public inputs = the inputs, then the outputs.  kind 8: a 256-entry table on inputs 0..255 (the tests use the Tip5 S-box table;
+        // any table exercises the same code, this one is out = (3 i^2 + 5 i + 7) mod 256); kind 9: a 10-entry table whose inputs are
+        // not their indices (the generator's search path, lookup.rs:160-168)
+        std::vector<std::pair<uint16_t, uint16_t>> table;
+        if (kind == 8) for (unsigned i = 0; i < 256; i++) table.push_back({(uint16_t)i, (uint16_t)((3 * i * i + 5 * i + 7) % 256)});
+        else for (unsigned i = 0; i < 10; i++) table.push_back({(uint16_t)(1000 + 37 * i), (uint16_t)(17 * i * i + 3)});
+        const size_t ti = b.add_lookup_table_from_pairs(table);
+        std::vector<Target> ins, outs;
+        for (size_t i = 0; i < param; i++) { Target t = b.add_virtual_target(); ins.push_back(t); outs.push_back(b.add_lookup_from_index(t, ti)); }
+        b.public_inputs = ins;
+        b.public_inputs.insert(b.public_inputs.end(), outs.begin(), outs.end());
+        cd.a_targets = ins;
     } else if (kind == 7) {
         // plonky2/examples/range_check.rs:20-24: the value is a public input and is range-checked to `param` (6) bits
         Target value = b.add_virtual_target();
@@ -521,6 +613,75 @@ static inline Witness generate_witness(const CircuitData& cd, const std::vector<
             for (int i = 0; i < 12; i++) put(Target::wire(row, PoseidonWires::OUTPUT + i), rowbuf[PoseidonWires::OUTPUT + i]);
             pos_done[k] = 1; progress = true;
         }
+    }
+    // LookupTableGenerator (lookup_table.rs:175-203): no dependencies; table entries fill the LUT rows upside down, padded with zeros
+    for (size_t li = 0; li < cd.lookup_rows.size(); li++) {
+        auto& lr = cd.lookup_rows[li]; auto& lut = cd.common.luts[li];
+        for (size_t row = lr.last_lut_gate; row <= lr.first_lut_gate; row++)
+            for (size_t sl = 0; sl < LOOKUP_TABLE_SLOTS; sl++) {
+                const size_t entry = (lr.first_lut_gate - row) * LOOKUP_TABLE_SLOTS + sl;
+                put(Target::wire(row, 3 * sl), entry < lut.size() ? lut[entry].first : 0);
+                put(Target::wire(row, 3 * sl + 1), entry < lut.size() ? lut[entry].second : 0);
+            }
+    }
+    // LookupGenerator (lookup.rs:151-175) needs the looking inputs, which other generators may produce: second fixed point
+    std::vector<char> lk_done(cd.lookup_slots.size(), 0);
+    for (bool progress = true; progress;) {
+        progress = false;
+        for (size_t k = 0; k < cd.lookup_slots.size(); k++) {
+            auto& ls = cd.lookup_slots[k];
+            Target tin = Target::wire(ls.row, 2 * ls.slot);
+            if (lk_done[k] || !is_set(tin)) continue;
+            const u64 v = canon(get(tin));
+            auto& lut = cd.common.luts[ls.lut];
+            size_t idx = 0;
+            if (v < lut.size() && lut[v].first == v) idx = v;
+            else { while (idx < lut.size() && lut[idx].first != v) idx++; assert(idx < lut.size() && "Incorrect input value provided"); }
+            put(Target::wire(ls.row, 2 * ls.slot + 1), lut[idx].second);
+            lk_done[k] = 1; progress = true;
+        }
+        // a lookup output may feed arithmetic / hashing: let those run again
+        for (size_t k = 0; k < cd.arith_ops.size(); k++) {
+            auto& op = cd.arith_ops[k];
+            Target t0 = Target::wire(op.row, 4 * op.slot), t1 = Target::wire(op.row, 4 * op.slot + 1), t2 = Target::wire(op.row, 4 * op.slot + 2);
+            if (arith_done[k] || !is_set(t0) || !is_set(t1) || !is_set(t2)) continue;
+            put(Target::wire(op.row, 4 * op.slot + 3), add(mul(mul(get(t0), get(t1)), op.c0), mul(get(t2), op.c1)));
+            arith_done[k] = 1; progress = true;
+        }
+        for (size_t k = 0; k < cd.poseidon_rows.size(); k++) {
+            const size_t row = cd.poseidon_rows[k];
+            if (pos_done[k]) continue;
+            bool ready = is_set(Target::wire(row, PoseidonWires::SWAP));
+            for (int i = 0; i < 12 && ready; i++) ready = is_set(Target::wire(row, PoseidonWires::INPUT + i));
+            if (!ready) continue;
+            u64 in[12];
+            for (int i = 0; i < 12; i++) in[i] = get(Target::wire(row, PoseidonWires::INPUT + i));
+            u64 swap = get(Target::wire(row, PoseidonWires::SWAP));
+            poseidon_gate_witness(in, swap, rowbuf.data());
+            for (int c = PoseidonWires::DELTA; c < PoseidonWires::END; c++) put(Target::wire(row, c), rowbuf[c]);
+            for (int i = 0; i < 12; i++) put(Target::wire(row, PoseidonWires::OUTPUT + i), rowbuf[PoseidonWires::OUTPUT + i]);
+            pos_done[k] = 1; progress = true;
+        }
+    }
+    for (char d : lk_done) assert(d && "a lookup never became ready");
+    // set_lookup_wires (prover.rs:34-99): multiplicities of the table entries, the last LookupGate padded with the first entry
+    for (size_t li = 0; li < cd.lookup_rows.size(); li++) {
+        auto& lr = cd.lookup_rows[li]; auto& lut = cd.common.luts[li];
+        std::vector<u64> mult(lut.size(), 0);
+        for (auto& lk : cd.lut_to_lookups[li]) {
+            const u64 v = canon(get(lk.first));
+            size_t idx = 0;
+            while (lut[idx].first != v) idx++;
+            mult[idx]++;
+        }
+        const size_t remaining = (LOOKUP_SLOTS - (cd.lut_to_lookups[li].size() % LOOKUP_SLOTS)) % LOOKUP_SLOTS;
+        for (size_t sl = LOOKUP_SLOTS - remaining; sl < LOOKUP_SLOTS; sl++) {
+            put(Target::wire(lr.last_lut_gate - 1, 2 * sl), lut[0].first);
+            put(Target::wire(lr.last_lut_gate - 1, 2 * sl + 1), lut[0].second);
+            mult[0]++;
+        }
+        for (size_t e = 0; e < lut.size(); e++)
+            put(Target::wire(lr.first_lut_gate - e / LOOKUP_TABLE_SLOTS, 3 * (e % LOOKUP_TABLE_SLOTS) + 2), mult[e]);
     }
     for (char d : arith_done) assert(d && "an arithmetic operation never became ready");
     for (char d : pos_done) assert(d && "a PoseidonGate never became ready");

@@ -29,13 +29,19 @@ template <> inline Ext2 kconst<Ext2>(u64 c) { return Ext2{c, 0}; }
 template <class K> static inline K ksbox(K x) { K x2 = kmul(x, x), x4 = kmul(x2, x2), x3 = kmul(x, x2); return kmul(x3, x4); }
 
 // (the numbering is the product's gl_circuit_desc.gate_types: 5 = BaseSumGate<2> with the 63 limbs of new_from_config)
-enum GateType { GATE_NOOP = 0, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON, GATE_BASE_SUM, GATE_NUM_TYPES };
+//  6 = LookupGate (40 (input, output) slots), 7 = LookupTableGate (26 (input, output, multiplicity) slots) of ONE lookup table
+enum GateType { GATE_NOOP = 0, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON, GATE_BASE_SUM, GATE_LOOKUP, GATE_LOOKUP_TABLE, GATE_NUM_TYPES };
+static const size_t LOOKUP_SLOTS = 40, LOOKUP_TABLE_SLOTS = 26;      // gates/lookup.rs:41-44 (routed / 2), gates/lookup_table.rs:47-50 (routed / 3)
+static const size_t NUM_COINS_LOOKUP = 4;                           // circuit_builder.rs:56-58: ChallengeA, ChallengeB, ChallengeAlpha, ChallengeDelta
+enum { LU_CH_A = 0, LU_CH_B = 1, LU_CH_ALPHA = 2, LU_CH_DELTA = 3 };
+enum { LU_SEL_TRANS_SRE = 0, LU_SEL_TRANS_LDC = 1, LU_SEL_INIT_SRE = 2, LU_SEL_LAST_LDC = 3, LU_SEL_START_END = 4 };      // gates/selectors.rs:34-40
 static const size_t BASE_SUM_LIMBS = 63;                 // gates/base_sum.rs:31-35: min(log_floor(p - 1, 2) = 63, num_routed_wires - 1 = 79)
 static const size_t UNUSED_SELECTOR = 0xFFFFFFFFull;     // selectors.rs:14
 
 static inline unsigned gate_degree(GateType g) {
     switch (g) { case GATE_NOOP: return 0; case GATE_CONSTANT: return 1; case GATE_PUBLIC_INPUT: return 1;
-                 case GATE_ARITHMETIC: return 3; case GATE_BASE_SUM: return 2 /* base_sum.rs:139-141 */; default: return 7; }
+                 case GATE_ARITHMETIC: return 3; case GATE_BASE_SUM: return 2 /* base_sum.rs:139-141 */;
+                 case GATE_LOOKUP: case GATE_LOOKUP_TABLE: return 0 /* lookup.rs:131-133, lookup_table.rs:150-152 */; default: return 7; }
 }
 static inline std::string gate_id(GateType g) {           // Gate::id(): the sort key next to the degree
     switch (g) {
@@ -44,12 +50,17 @@ static inline std::string gate_id(GateType g) {           // Gate::id(): the sor
         case GATE_PUBLIC_INPUT: return "PublicInputGate";
         case GATE_ARITHMETIC: return "ArithmeticGate { num_ops: 20 }";
         case GATE_BASE_SUM: return "BaseSumGate { num_limbs: 63 } + Base: 2";          // base_sum.rs:49-51
+        // format!("{self:?}") of the gate structs (lookup.rs:55-57, lookup_table.rs:66-68); with ONE table the prefixes decide every
+        // comparison against the other gate types of degree 0 ("LookupGate {" < "LookupTableGate {" < "NoopGate")
+        case GATE_LOOKUP: return "LookupGate { num_slots: 40, lut: [";
+        case GATE_LOOKUP_TABLE: return "LookupTableGate { num_slots: 26, lut: [";
         default: return "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>";
     }
 }
 static inline size_t gate_num_constraints(GateType g) {
     switch (g) { case GATE_NOOP: return 0; case GATE_CONSTANT: return 2; case GATE_PUBLIC_INPUT: return 4;
                  case GATE_ARITHMETIC: return 20; case GATE_BASE_SUM: return 1 + BASE_SUM_LIMBS /* base_sum.rs:144-146 */;
+                 case GATE_LOOKUP: case GATE_LOOKUP_TABLE: return 0;          // "No main trace constraints for lookups" (lookup.rs:72-75)
                  default: return 123; }   // poseidon.rs:403-409
 }
 
@@ -164,6 +175,7 @@ struct SelectorsInfo {
     std::vector<size_t> selector_indices;        // per gate: which selector polynomial
     std::vector<std::pair<size_t, size_t>> groups;   // [start, end) ranges of gate indices
     size_t num_selectors() const { return groups.size(); }
+    size_t num_lookup_selectors = 0;             // lookup selector columns between the gate selectors and the gates' constants
     size_t gate_index(GateType g) const { for (size_t i = 0; i < gates.size(); i++) if (gates[i] == g) return i; assert(false); return 0; }
 };
 
@@ -182,14 +194,14 @@ static inline void evaluate_gate_constraints(const SelectorsInfo& si, size_t num
                                              const K* local_constants, const K* wires, const u64* pi_hash, K* out) {
     for (size_t i = 0; i < num_gate_constraints; i++) out[i] = kconst<K>(0);
     const size_t nsel = si.num_selectors();
-    const K* gc = local_constants + nsel;          // vars.remove_prefix(num_selectors), no lookup selectors here
+    const K* gc = local_constants + nsel + si.num_lookup_selectors;       // vars.remove_prefix(num_selectors + num_lookup_selectors) (gate.rs:129-133)
     K tmp[123];
     for (size_t gi = 0; gi < si.gates.size(); gi++) {
         const size_t sel = si.selector_indices[gi];
         K filter = compute_filter<K>(gi, si.groups[sel], local_constants[sel], nsel > 1);
         size_t nc = gate_num_constraints(si.gates[gi]);
         switch (si.gates[gi]) {
-            case GATE_NOOP: break;
+            case GATE_NOOP: case GATE_LOOKUP: case GATE_LOOKUP_TABLE: break;
             case GATE_CONSTANT: eval_constant<K>(gc, wires, tmp); break;
             case GATE_PUBLIC_INPUT: eval_public_input<K>(pi_hash, wires, tmp); break;
             case GATE_ARITHMETIC: eval_arithmetic<K>(gc, wires, tmp); break;

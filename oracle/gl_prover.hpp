@@ -69,6 +69,7 @@ struct FriProof {
 };
 struct OpeningSet {
     std::vector<Ext2> constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys;
+    std::vector<Ext2> lookup_zs, lookup_zs_next;          // empty without lookups (proof.rs:300-301)
 };
 struct Proof {
     std::vector<Digest> wires_cap, zs_pp_cap, quotient_cap;
@@ -78,7 +79,7 @@ struct Proof {
 };
 // intermediates kept for parity tests against the HIP path
 struct ProverTrace {
-    std::vector<u64> betas, gammas, alphas; Ext2 zeta, fri_alpha; std::vector<Ext2> fri_betas;
+    std::vector<u64> betas, gammas, alphas, deltas; Ext2 zeta, fri_alpha; std::vector<Ext2> fri_betas;
     std::vector<std::vector<u64>> zs_partial_products;     // 20 columns of values
     std::vector<std::vector<u64>> quotient_chunks;         // 16 columns of coefficients
     std::vector<Ext2> final_poly_coeffs_initial;           // alpha^2 Q0 + Q1 before the LDE (n coefficients)
@@ -170,18 +171,122 @@ static inline void check_partial_products(const K* num, const K* den, size_t R, 
     (void)num_prods;
 }
 
+// ---- lookup argument (log-derivative, Tip5 layout) -------------------------------------------------------------------
+// get_lut_poly(...).eval(delta) (vanishing_poly.rs:31-49): the table's combos (inp + b * out), zero-padded to `degree` entries and
+// REVERSED, as coefficients of a polynomial evaluated at the delta challenge: sum_i combo_i * delta^(degree - 1 - i)
+static inline u64 lut_poly_eval(const std::vector<std::pair<uint16_t, uint16_t>>& lut, u64 b, u64 delta, size_t degree) {
+    u64 acc = 0;                                         // Horner from the highest coefficient = combo_0
+    for (size_t i = 0; i < degree; i++) acc = add(mul(acc, delta), i < lut.size() ? add(lut[i].first, mul(b, lut[i].second)) : 0);
+    return acc;
+}
+// check_lookup_constraints (vanishing_poly.rs:337-500 / 503-670), generic over the field: 4 + #tables + 2 * #SLDC constraints
+template <class K>
+static inline void check_lookup_constraints(const CommonData& cm, const K* wires, const K* local_lookup_zs, const K* next_lookup_zs,
+                                            const K* lookup_selectors, const u64* deltas /* 4 */, std::vector<K>& out) {
+    const size_t lu_degree = cm.quotient_degree_factor - 1, num_sldc = cm.num_lookup_polys - 1;
+    const size_t lut_degree = (LOOKUP_TABLE_SLOTS + num_sldc - 1) / num_sldc;
+    const K z_re = local_lookup_zs[0], next_z_re = next_lookup_zs[0];
+    const K* z_x = local_lookup_zs + 1; const K* z_gx = next_lookup_zs + 1;
+    const u64 ca = deltas[LU_CH_A], cb = deltas[LU_CH_B], calpha = deltas[LU_CH_ALPHA], cdelta = deltas[LU_CH_DELTA];
+    std::vector<K> looked(LOOKUP_TABLE_SLOTS), looking(LOOKUP_SLOTS), lookup_combo(LOOKUP_TABLE_SLOTS);
+    for (size_t sl = 0; sl < LOOKUP_TABLE_SLOTS; sl++) {
+        looked[sl] = kadd(wires[3 * sl], kscal(wires[3 * sl + 1], ca));
+        lookup_combo[sl] = kadd(wires[3 * sl], kscal(wires[3 * sl + 1], cb));
+    }
+    for (size_t sl = 0; sl < LOOKUP_SLOTS; sl++) looking[sl] = kadd(wires[2 * sl], kscal(wires[2 * sl + 1], ca));
+    out.push_back(kmul(lookup_selectors[LU_SEL_LAST_LDC], z_x[num_sldc - 1]));          // last LDC
+    out.push_back(kmul(lookup_selectors[LU_SEL_INIT_SRE], z_x[0]));                     // initial Sum
+    out.push_back(kmul(lookup_selectors[LU_SEL_INIT_SRE], z_re));                       // initial RE
+    for (size_t r = LU_SEL_START_END; r < cm.num_lookup_selectors; r++) {               // final RE, one per table
+        auto& lut = cm.luts[r - LU_SEL_START_END];
+        const size_t rows = (lut.size() + LOOKUP_TABLE_SLOTS - 1) / LOOKUP_TABLE_SLOTS;
+        const u64 f = lut_poly_eval(lut, cb, cdelta, LOOKUP_TABLE_SLOTS * rows);
+        out.push_back(kmul(lookup_selectors[r], ksub(z_re, kconst<K>(f))));
+    }
+    K cur = next_z_re;                                                                   // RE row transition
+    for (size_t sl = 0; sl < LOOKUP_TABLE_SLOTS; sl++) cur = kadd(kscal(cur, cdelta), lookup_combo[sl]);
+    out.push_back(kmul(lookup_selectors[LU_SEL_TRANS_SRE], ksub(z_re, cur)));
+    const K alpha = kconst<K>(calpha);
+    for (size_t poly = 0; poly < num_sldc; poly++) {
+        const size_t t0 = poly * lut_degree, t1 = std::min((poly + 1) * lut_degree, LOOKUP_TABLE_SLOTS);
+        const size_t u0 = poly * lu_degree, u1 = std::min((poly + 1) * lu_degree, LOOKUP_SLOTS);
+        K lut_prod = kconst<K>(1), lu_prod = kconst<K>(1);
+        for (size_t i = t0; i < t1; i++) lut_prod = kmul(lut_prod, ksub(alpha, looked[i]));
+        for (size_t i = u0; i < u1; i++) lu_prod = kmul(lu_prod, ksub(alpha, looking[i]));
+        K lu_sum_prods = kconst<K>(0), lut_sum_prods_mul = kconst<K>(0);
+        for (size_t i = u0; i < u1; i++) {
+            K pr = kconst<K>(1);
+            for (size_t j = u0; j < u1; j++) if (j != i) pr = kmul(pr, ksub(alpha, looking[j]));
+            lu_sum_prods = kadd(lu_sum_prods, pr);
+        }
+        for (size_t i = t0; i < t1; i++) {
+            K pr = kconst<K>(1);
+            for (size_t j = t0; j < t1; j++) if (j != i) pr = kmul(pr, ksub(alpha, looked[j]));
+            lut_sum_prods_mul = kadd(lut_sum_prods_mul, kmul(wires[3 * i + 2], pr));
+        }
+        const K prev = poly == 0 ? z_gx[num_sldc - 1] : z_x[poly - 1];
+        out.push_back(kmul(lookup_selectors[LU_SEL_TRANS_SRE], ksub(kmul(lut_prod, ksub(z_x[poly], prev)), lut_sum_prods_mul)));
+        out.push_back(kmul(lookup_selectors[LU_SEL_TRANS_LDC], kadd(kmul(lu_prod, ksub(z_x[poly], prev)), lu_sum_prods)));
+    }
+}
+
+// compute_lookup_polys (prover.rs:425-541) for one challenge: RE and the partial SLDC polynomials as value columns
+static inline std::vector<std::vector<u64>> compute_lookup_polys(const CircuitData& cd, const Witness& w, const u64* deltas /* 4 */) {
+    const CommonData& cm = cd.common;
+    const size_t degree = cm.degree(), max_lookup_degree = cm.config.max_quotient_degree_factor - 1;
+    const size_t num_partial = (LOOKUP_SLOTS + max_lookup_degree - 1) / max_lookup_degree;
+    const size_t max_table_degree = (LOOKUP_TABLE_SLOTS + num_partial - 1) / num_partial;
+    std::vector<std::vector<u64>> polys(num_partial + 1, std::vector<u64>(degree, 0));
+    auto wire = [&](size_t row, size_t col) { return w.wire_values[col][row]; };
+    for (auto& lr : cd.lookup_rows) {
+        for (size_t row = lr.first_lut_gate + 1; row-- > lr.last_lut_gate;) {           // partial Sums and RE, from the first LUT row down
+            std::vector<u64> minus(LOOKUP_TABLE_SLOTS);
+            for (size_t sl = 0; sl < LOOKUP_TABLE_SLOTS; sl++)
+                minus[sl] = sub(deltas[LU_CH_ALPHA], add(wire(row, 3 * sl), mul(deltas[LU_CH_A], wire(row, 3 * sl + 1))));
+            std::vector<u64> inv_c = batch_inverse(minus);
+            u64 new_re = polys[0][row + 1];
+            for (size_t sl = 0; sl < LOOKUP_TABLE_SLOTS; sl++)
+                new_re = add(mul(new_re, deltas[LU_CH_DELTA]), add(wire(row, 3 * sl), mul(deltas[LU_CH_B], wire(row, 3 * sl + 1))));
+            polys[0][row] = new_re;
+            for (size_t slot = 0; slot < num_partial; slot++) {
+                u64 sum = slot != 0 ? polys[slot][row] : polys[num_partial][row + 1];
+                for (size_t sl = slot * max_table_degree; sl < std::min((slot + 1) * max_table_degree, LOOKUP_TABLE_SLOTS); sl++)
+                    sum = add(sum, mul(wire(row, 3 * sl + 2), inv_c[sl]));
+                polys[slot + 1][row] = sum;
+            }
+        }
+        for (size_t row = lr.last_lut_gate; row-- > lr.last_lu_gate;) {                 // partial LDCs
+            std::vector<u64> minus(LOOKUP_SLOTS);
+            for (size_t sl = 0; sl < LOOKUP_SLOTS; sl++)
+                minus[sl] = sub(deltas[LU_CH_ALPHA], add(wire(row, 2 * sl), mul(deltas[LU_CH_A], wire(row, 2 * sl + 1))));
+            std::vector<u64> inv_c = batch_inverse(minus);
+            for (size_t slot = 0; slot < num_partial; slot++) {
+                const u64 prev = slot == 0 ? polys[num_partial][row + 1] : polys[slot][row];
+                u64 sum = 0;
+                for (size_t sl = slot * max_lookup_degree; sl < std::min((slot + 1) * max_lookup_degree, LOOKUP_SLOTS); sl++) sum = add(sum, inv_c[sl]);
+                polys[slot + 1][row] = sub(prev, sum);
+            }
+        }
+    }
+    return polys;
+}
+
 // Values of the vanishing combination at one point, for each alpha (vanishing_poly.rs:54-160 / 164-330)
 template <class K>
 static inline std::vector<K> eval_vanishing_poly(const CommonData& cm, K x, K l_0_x, const K* local_constants, const K* wires,
                                                  const u64* pi_hash, const K* local_zs, const K* next_zs, const K* partial_products,
                                                  const K* s_sigmas, const std::vector<u64>& betas, const std::vector<u64>& gammas,
-                                                 const std::vector<u64>& alphas) {
+                                                 const std::vector<u64>& alphas, const K* local_lookup_zs = nullptr, const K* next_lookup_zs = nullptr,
+                                                 const std::vector<u64>& deltas = std::vector<u64>()) {
     const size_t R = cm.config.num_routed_wires, nch = cm.config.num_challenges, np = cm.num_partial_products;
-    std::vector<K> z1_terms, pp_terms, constraint_terms(cm.num_gate_constraints);
+    std::vector<K> z1_terms, pp_terms, lookup_terms, constraint_terms(cm.num_gate_constraints);
     evaluate_gate_constraints<K>(cm.selectors, cm.num_gate_constraints, local_constants, wires, pi_hash, constraint_terms.data());
     std::vector<K> num(R), den(R);
     for (size_t i = 0; i < nch; i++) {
         z1_terms.push_back(kmul(l_0_x, ksub(local_zs[i], kconst<K>(1))));
+        if (cm.num_lookup_polys)                             // vanishing_poly.rs:263-281
+            check_lookup_constraints<K>(cm, wires, local_lookup_zs + i * cm.num_lookup_polys, next_lookup_zs + i * cm.num_lookup_polys,
+                                        local_constants + cm.selectors.num_selectors(), deltas.data() + NUM_COINS_LOOKUP * i, lookup_terms);
         for (size_t j = 0; j < R; j++) {
             num[j] = kadd(kadd(wires[j], kscal(kscal(x, cm.k_is[j]), betas[i])), kconst<K>(gammas[i]));
             den[j] = kadd(kadd(wires[j], kscal(s_sigmas[j], betas[i])), kconst<K>(gammas[i]));
@@ -191,6 +296,7 @@ static inline std::vector<K> eval_vanishing_poly(const CommonData& cm, K x, K l_
     std::vector<K> terms;
     terms.insert(terms.end(), z1_terms.begin(), z1_terms.end());
     terms.insert(terms.end(), pp_terms.begin(), pp_terms.end());
+    terms.insert(terms.end(), lookup_terms.begin(), lookup_terms.end());
     terms.insert(terms.end(), constraint_terms.begin(), constraint_terms.end());
     std::vector<K> res(alphas.size(), kconst<K>(0));                      // reduce_with_powers_multi (plonk_common.rs:97-114)
     for (size_t t = terms.size(); t-- > 0;)
@@ -201,7 +307,8 @@ static inline std::vector<K> eval_vanishing_poly(const CommonData& cm, K x, K l_
 // compute_quotient_polys (prover.rs:576-744) + split into chunks (:245-258): 16 coefficient vectors of length n
 static inline bool compute_quotient_chunks(const CircuitData& cd, const PolynomialBatch& wires_c, const PolynomialBatch& zs_c,
                                            const Digest& pi_hash, const std::vector<u64>& betas, const std::vector<u64>& gammas,
-                                           const std::vector<u64>& alphas, unsigned threads, std::vector<std::vector<u64>>& out) {
+                                           const std::vector<u64>& alphas, unsigned threads, std::vector<std::vector<u64>>& out,
+                                           const std::vector<u64>& deltas = std::vector<u64>()) {
     const CommonData& cm = cd.common;
     const unsigned qbits = log2_ceil(cm.quotient_degree_factor);
     assert(qbits == cm.config.rate_bits && "restatement covers step = 1 only");
@@ -221,7 +328,8 @@ static inline bool compute_quotient_chunks(const CircuitData& cd, const Polynomi
             const u64* zl = zs_c.get_lde_values(i, 1);
             const u64* zn = zs_c.get_lde_values((i + next_step) % lde, 1);
             u64 l0 = zh.eval_l_0(i, x);
-            std::vector<u64> r = eval_vanishing_poly<u64>(cm, x, l0, cs, wr, pih, zl, zn, zl + nch, cs + nc, betas, gammas, alphas);
+            const size_t lk = nch * (1 + np);                     // lookup polynomials sit behind Z and the partial products (circuit_data.rs:450-459)
+            std::vector<u64> r = eval_vanishing_poly<u64>(cm, x, l0, cs, wr, pih, zl, zn, zl + nch, cs + nc, betas, gammas, alphas, zl + lk, zn + lk, deltas);
             u64 di = zh.eval_inverse(i);
             for (size_t a = 0; a < nch; a++) qvals[a][i] = mul(r[a], di);
         }
@@ -273,6 +381,13 @@ static inline bool prove(const CircuitData& cd, const Witness& w, unsigned threa
     std::vector<u64> betas, gammas, alphas;
     for (size_t i = 0; i < nch; i++) betas.push_back(ch.challenge());
     for (size_t i = 0; i < nch; i++) gammas.push_back(ch.challenge());
+    // lookups: 4 coins per challenge, betas and gammas reused for the first ones (prover.rs:166-184): [betas | gammas | additional]
+    const bool has_lookup = !cm.luts.empty();
+    std::vector<u64> deltas;
+    if (has_lookup) {
+        deltas = betas; deltas.insert(deltas.end(), gammas.begin(), gammas.end());
+        for (size_t i = 0; i < NUM_COINS_LOOKUP * nch - 2 * nch; i++) deltas.push_back(ch.challenge());
+    }
     // Z first, then all partial products (prover.rs:189-200)
     std::vector<std::vector<u64>> zs, pps;
     for (size_t i = 0; i < nch; i++) {
@@ -282,11 +397,13 @@ static inline bool prove(const CircuitData& cd, const Witness& w, unsigned threa
     }
     std::vector<std::vector<u64>> zs_pp = zs;
     zs_pp.insert(zs_pp.end(), pps.begin(), pps.end());
+    if (has_lookup)                                          // compute_all_lookup_polys (prover.rs:543-572), appended (:206-211)
+        for (size_t i = 0; i < nch; i++) for (auto& col : compute_lookup_polys(cd, w, deltas.data() + NUM_COINS_LOOKUP * i)) zs_pp.push_back(col);
     PolynomialBatch zs_c = batch_from_values(zs_pp, cfg.rate_bits, cfg.cap_height, threads);
     ch.observe_cap(cap_of(zs_c));
     for (size_t i = 0; i < nch; i++) alphas.push_back(ch.challenge());
     std::vector<std::vector<u64>> qchunks;
-    if (!compute_quotient_chunks(cd, wires_c, zs_c, pi_hash, betas, gammas, alphas, threads, qchunks)) return false;
+    if (!compute_quotient_chunks(cd, wires_c, zs_c, pi_hash, betas, gammas, alphas, threads, qchunks, deltas)) return false;
     PolynomialBatch quot_c = batch_from_coeffs(qchunks, cfg.rate_bits, cfg.cap_height, threads);
     ch.observe_cap(cap_of(quot_c));
     Ext2 zeta = ch.ext_challenge();
@@ -307,11 +424,15 @@ static inline bool prove(const CircuitData& cd, const Witness& w, unsigned threa
     os.wires = eval_all(wires_c, zeta);
     os.plonk_zs.assign(zs_eval.begin(), zs_eval.begin() + nch);
     os.plonk_zs_next.assign(zs_next.begin(), zs_next.begin() + nch);
-    os.partial_products.assign(zs_eval.begin() + nch, zs_eval.end());
+    const size_t nzp = nch * (1 + cm.num_partial_products);      // Z's and partial products; lookup polynomials follow
+    os.partial_products.assign(zs_eval.begin() + nch, zs_eval.begin() + nzp);
+    os.lookup_zs.assign(zs_eval.begin() + nzp, zs_eval.end());
+    os.lookup_zs_next.assign(zs_next.begin() + nzp, zs_next.end());
     os.quotient_polys = eval_all(quot_c, zeta);
-    // observe_openings (fri/challenges.rs:15-22; proof.rs:345-381)
-    for (auto* v : {&os.constants, &os.plonk_sigmas, &os.wires, &os.plonk_zs, &os.partial_products, &os.quotient_polys}) for (auto& e : *v) ch.observe_ext(e);
+    // observe_openings (fri/challenges.rs:15-22; proof.rs:345-381): zeta batch [.., quotient, lookup_zs], then [zs_next, lookup_zs_next]
+    for (auto* v : {&os.constants, &os.plonk_sigmas, &os.wires, &os.plonk_zs, &os.partial_products, &os.quotient_polys, &os.lookup_zs}) for (auto& e : *v) ch.observe_ext(e);
     for (auto& e : os.plonk_zs_next) ch.observe_ext(e);
+    for (auto& e : os.lookup_zs_next) ch.observe_ext(e);
 
     // prove_openings (fri/oracle.rs:162-219)
     Ext2 alpha = ch.ext_challenge();
@@ -323,8 +444,11 @@ static inline bool prove(const CircuitData& cd, const Witness& w, unsigned threa
     };
     {
         std::vector<const std::vector<u64>*> batch0, batch1;
-        for (int o = 0; o < 4; o++) for (auto& p : oracles[o]->polynomials) batch0.push_back(&p);
+        // fri_all_polys / fri_next_batch_polys (circuit_data.rs:564-597): lookup polynomials come LAST in both batches
+        for (int o = 0; o < 4; o++) for (size_t c = 0; c < (o == 2 ? nzp : oracles[o]->polynomials.size()); c++) batch0.push_back(&oracles[o]->polynomials[c]);
+        for (size_t c = nzp; c < zs_c.polynomials.size(); c++) batch0.push_back(&zs_c.polynomials[c]);
         for (size_t i = 0; i < nch; i++) batch1.push_back(&zs_c.polynomials[i]);
+        for (size_t c = nzp; c < zs_c.polynomials.size(); c++) batch1.push_back(&zs_c.polynomials[c]);
         std::vector<Ext2> q0 = reduce_and_divide(batch0, zeta);
         final_poly = q0;                                  // shift of the empty polynomial is a no-op
         std::vector<Ext2> q1 = reduce_and_divide(batch1, gzeta);
@@ -392,7 +516,7 @@ static inline bool prove(const CircuitData& cd, const Witness& w, unsigned threa
     proof.wires_cap = cap_of(wires_c); proof.zs_pp_cap = cap_of(zs_c); proof.quotient_cap = cap_of(quot_c);
     proof.public_inputs = w.public_inputs;
     if (trace) {
-        trace->betas = betas; trace->gammas = gammas; trace->alphas = alphas; trace->zeta = zeta; trace->fri_alpha = alpha;
+        trace->betas = betas; trace->gammas = gammas; trace->alphas = alphas; trace->deltas = deltas; trace->zeta = zeta; trace->fri_alpha = alpha;
         trace->fri_betas = fri_betas; trace->zs_partial_products = zs_pp; trace->quotient_chunks = qchunks;
         trace->query_indices = idx; trace->public_inputs_hash = pi_hash;
     }
@@ -409,9 +533,10 @@ static inline void put_merkle_proof(std::vector<uint8_t>& o, const std::vector<D
 static inline std::vector<uint8_t> proof_to_bytes(const Proof& p) {
     std::vector<uint8_t> o;
     put_cap(o, p.wires_cap); put_cap(o, p.zs_pp_cap); put_cap(o, p.quotient_cap);
-    const OpeningSet& os = p.openings;                                            // :1409-1423 (lookup vectors are empty)
+    const OpeningSet& os = p.openings;                                            // :1409-1423
     put_ext_vec(o, os.constants); put_ext_vec(o, os.plonk_sigmas); put_ext_vec(o, os.wires); put_ext_vec(o, os.plonk_zs);
-    put_ext_vec(o, os.plonk_zs_next); put_ext_vec(o, os.partial_products); put_ext_vec(o, os.quotient_polys);
+    put_ext_vec(o, os.plonk_zs_next); put_ext_vec(o, os.lookup_zs); put_ext_vec(o, os.lookup_zs_next);      // lookup vectors before the partial products
+    put_ext_vec(o, os.partial_products); put_ext_vec(o, os.quotient_polys);
     const FriProof& f = p.opening_proof;
     for (auto& c : f.commit_phase_merkle_caps) put_cap(o, c);
     for (auto& qr : f.query_round_proofs) {
@@ -437,12 +562,13 @@ static inline bool proof_from_bytes(const CommonData& cm, const uint8_t* b, size
     if (!get_digests(p.wires_cap, ncap) || !get_digests(p.zs_pp_cap, ncap) || !get_digests(p.quotient_cap, ncap)) return false;
     OpeningSet& os = p.openings;
     if (!get_ext(os.constants, cm.num_constants) || !get_ext(os.plonk_sigmas, cfg.num_routed_wires) || !get_ext(os.wires, cfg.num_wires) ||
-        !get_ext(os.plonk_zs, nch) || !get_ext(os.plonk_zs_next, nch) || !get_ext(os.partial_products, nch * cm.num_partial_products) ||
+        !get_ext(os.plonk_zs, nch) || !get_ext(os.plonk_zs_next, nch) || !get_ext(os.lookup_zs, nch * cm.num_lookup_polys) ||
+        !get_ext(os.lookup_zs_next, nch * cm.num_lookup_polys) || !get_ext(os.partial_products, nch * cm.num_partial_products) ||
         !get_ext(os.quotient_polys, nch * cm.quotient_degree_factor)) return false;
     FriProof& f = p.opening_proof;
     f.commit_phase_merkle_caps.resize(cm.fri_reduction_arity_bits.size());
     for (auto& c : f.commit_phase_merkle_caps) if (!get_digests(c, ncap)) return false;
-    const size_t widths[4] = {cm.num_constants + cfg.num_routed_wires, cfg.num_wires, nch * (1 + cm.num_partial_products), nch * cm.quotient_degree_factor};
+    const size_t widths[4] = {cm.num_constants + cfg.num_routed_wires, cfg.num_wires, nch * (1 + cm.num_partial_products + cm.num_lookup_polys), nch * cm.quotient_degree_factor};
     f.query_round_proofs.resize(cfg.num_query_rounds);
     for (auto& qr : f.query_round_proofs) {
         qr.initial.resize(4);
@@ -479,6 +605,7 @@ static inline const char* verify(const CommonData& cm, const std::vector<Digest>
     if (p.wires_cap.size() != (size_t(1) << cfg.cap_height) || os.wires.size() != cfg.num_wires || os.constants.size() != cm.num_constants ||
         os.plonk_sigmas.size() != cfg.num_routed_wires || os.plonk_zs.size() != nch || os.plonk_zs_next.size() != nch ||
         os.partial_products.size() != nch * cm.num_partial_products || os.quotient_polys.size() != nch * cm.quotient_degree_factor ||
+        os.lookup_zs.size() != nch * cm.num_lookup_polys || os.lookup_zs_next.size() != nch * cm.num_lookup_polys ||
         fp.commit_phase_merkle_caps.size() != cm.fri_reduction_arity_bits.size() || fp.query_round_proofs.size() != cfg.num_query_rounds ||
         fp.final_poly.size() != cm.final_poly_len() || p.public_inputs.size() != cm.num_public_inputs)
         return "malformed proof";
@@ -489,12 +616,18 @@ static inline const char* verify(const CommonData& cm, const std::vector<Digest>
     std::vector<u64> betas, gammas, alphas;
     for (size_t i = 0; i < nch; i++) betas.push_back(ch.challenge());
     for (size_t i = 0; i < nch; i++) gammas.push_back(ch.challenge());
+    std::vector<u64> deltas;
+    if (cm.num_lookup_polys) {
+        deltas = betas; deltas.insert(deltas.end(), gammas.begin(), gammas.end());
+        for (size_t i = 0; i < NUM_COINS_LOOKUP * nch - 2 * nch; i++) deltas.push_back(ch.challenge());
+    }
     ch.observe_cap(p.zs_pp_cap);
     for (size_t i = 0; i < nch; i++) alphas.push_back(ch.challenge());
     ch.observe_cap(p.quotient_cap);
     Ext2 zeta = ch.ext_challenge();
-    for (auto* v : {&os.constants, &os.plonk_sigmas, &os.wires, &os.plonk_zs, &os.partial_products, &os.quotient_polys}) for (auto& e : *v) ch.observe_ext(e);
+    for (auto* v : {&os.constants, &os.plonk_sigmas, &os.wires, &os.plonk_zs, &os.partial_products, &os.quotient_polys, &os.lookup_zs}) for (auto& e : *v) ch.observe_ext(e);
     for (auto& e : os.plonk_zs_next) ch.observe_ext(e);
+    for (auto& e : os.lookup_zs_next) ch.observe_ext(e);
     Ext2 fri_alpha = ch.ext_challenge();
     std::vector<Ext2> fri_betas;
     for (auto& cap : fp.commit_phase_merkle_caps) { ch.observe_cap(cap); fri_betas.push_back(ch.ext_challenge()); }
@@ -508,7 +641,8 @@ static inline const char* verify(const CommonData& cm, const std::vector<Digest>
     Ext2 zeta_n = eexp_pow2(zeta, cm.degree_bits), z_h = esub(zeta_n, ext(1));
     Ext2 l0 = eeq(zeta, ext(1)) ? ext(1) : emul(z_h, einv(escalar(esub(zeta, ext(1)), (u64)n)));    // plonk_common.rs:61-71
     std::vector<Ext2> van = eval_vanishing_poly<Ext2>(cm, zeta, l0, os.constants.data(), os.wires.data(), pih, os.plonk_zs.data(),
-                                                      os.plonk_zs_next.data(), os.partial_products.data(), os.plonk_sigmas.data(), betas, gammas, alphas);
+                                                      os.plonk_zs_next.data(), os.partial_products.data(), os.plonk_sigmas.data(), betas, gammas, alphas,
+                                                      os.lookup_zs.data(), os.lookup_zs_next.data(), deltas);
     for (size_t i = 0; i < nch; i++) {
         Ext2 t{0, 0};
         for (size_t k = cm.quotient_degree_factor; k-- > 0;) t = eadd(emul(t, zeta_n), os.quotient_polys[i * cm.quotient_degree_factor + k]);
@@ -521,10 +655,13 @@ static inline const char* verify(const CommonData& cm, const std::vector<Digest>
     // PrecomputedReducedOpenings (fri/verifier.rs:243-260)
     auto reduce = [&](const std::vector<Ext2>& vals) { Ext2 acc{0, 0}; for (size_t i = vals.size(); i-- > 0;) acc = eadd(emul(acc, fri_alpha), vals[i]); return acc; };
     std::vector<Ext2> batch0;
-    for (auto* v : {&os.constants, &os.plonk_sigmas, &os.wires, &os.plonk_zs, &os.partial_products, &os.quotient_polys}) batch0.insert(batch0.end(), v->begin(), v->end());
-    Ext2 red0 = reduce(batch0), red1 = reduce(os.plonk_zs_next);
+    for (auto* v : {&os.constants, &os.plonk_sigmas, &os.wires, &os.plonk_zs, &os.partial_products, &os.quotient_polys, &os.lookup_zs}) batch0.insert(batch0.end(), v->begin(), v->end());
+    std::vector<Ext2> batch1v = os.plonk_zs_next;
+    batch1v.insert(batch1v.end(), os.lookup_zs_next.begin(), os.lookup_zs_next.end());
+    Ext2 red0 = reduce(batch0), red1 = reduce(batch1v);
     const std::vector<Digest>* caps[4] = {&constants_sigmas_cap, &p.wires_cap, &p.zs_pp_cap, &p.quotient_cap};
-    const size_t widths[4] = {cm.num_constants + cfg.num_routed_wires, cfg.num_wires, nch * (1 + cm.num_partial_products), nch * cm.quotient_degree_factor};
+    const size_t nzp = nch * (1 + cm.num_partial_products);
+    const size_t widths[4] = {cm.num_constants + cfg.num_routed_wires, cfg.num_wires, nzp + nch * cm.num_lookup_polys, nch * cm.quotient_degree_factor};
     const unsigned log_n = cm.degree_bits + cfg.rate_bits;
     for (unsigned q = 0; q < cfg.num_query_rounds; q++) {
         const FriQueryRound& qr = fp.query_round_proofs[q];
@@ -538,8 +675,10 @@ static inline const char* verify(const CommonData& cm, const std::vector<Digest>
         // fri_combine_initial (fri/verifier.rs:124-165)
         Ext2 sx{subgroup_x, 0};
         std::vector<Ext2> ev0, ev1;
-        for (int o = 0; o < 4; o++) for (u64 v : qr.initial[o].first) ev0.push_back(Ext2{v, 0});
+        for (int o = 0; o < 4; o++) for (size_t c = 0; c < (o == 2 ? nzp : widths[o]); c++) ev0.push_back(Ext2{qr.initial[o].first[c], 0});
+        for (size_t c = nzp; c < widths[2]; c++) ev0.push_back(Ext2{qr.initial[2].first[c], 0});      // lookup polynomials last
         for (size_t i = 0; i < nch; i++) ev1.push_back(Ext2{qr.initial[2].first[i], 0});
+        for (size_t c = nzp; c < widths[2]; c++) ev1.push_back(Ext2{qr.initial[2].first[c], 0});
         Ext2 sum = emul(esub(reduce(ev0), red0), einv(esub(sx, zeta)));
         sum = emul(sum, eexp_u64(fri_alpha, ev1.size()));
         sum = eadd(sum, emul(esub(reduce(ev1), red1), einv(esub(sx, gzeta))));

@@ -270,6 +270,10 @@ static void sink_fri_config(ByteSink& o, const CircuitConfig& c) {
     o.usize(c.rate_bits); o.usize(c.cap_height); o.usize(c.num_query_rounds); o.word32(c.proof_of_work_bits);
     o.byte(1); o.usize(c.fri_arity_bits); o.usize(c.fri_final_poly_bits);                  // ConstantArityBits
 }
+static void sink_lut(ByteSink& o, const std::vector<std::pair<uint16_t, uint16_t>>& lut) {      // write_lut (mod.rs:2077-2085)
+    o.usize(lut.size());
+    for (auto& e : lut) { o.byte((uint8_t)e.first); o.byte((uint8_t)(e.first >> 8)); o.byte((uint8_t)e.second); o.byte((uint8_t)(e.second >> 8)); }
+}
 static void sink_common(ByteSink& o, const CommonData& cm) {
     const CircuitConfig& c = cm.config;
     o.usize(c.num_wires); o.usize(c.num_routed_wires); o.usize(c.num_constants); o.usize(100 /* security_bits, circuit_data.rs:77 */); o.usize(c.num_challenges);
@@ -286,6 +290,8 @@ static void sink_common(ByteSink& o, const CommonData& cm) {
             case GATE_NOOP: o.word32(9); break;
             case GATE_POSEIDON: o.word32(11); break;
             case GATE_BASE_SUM: o.word32(2); o.usize(BASE_SUM_LIMBS); break;              // BaseSumGate<2>: write_usize(num_limbs) (base_sum.rs:53-55)
+            case GATE_LOOKUP: o.word32(6); o.usize(LOOKUP_SLOTS); sink_lut(o, cm.luts[0]); break;                    // lookup.rs:59-62
+            case GATE_LOOKUP_TABLE: o.word32(7); o.usize(LOOKUP_TABLE_SLOTS); sink_lut(o, cm.luts[0]); o.usize(cm.last_lut_row); break;   // lookup_table.rs:70-74
             default: o.word32(12); break;                                                  // PublicInputGate
         }
     }
@@ -294,7 +300,8 @@ static void sink_common(ByteSink& o, const CommonData& cm) {
     o.usize(cm.quotient_degree_factor); o.usize(cm.num_gate_constraints); o.usize(cm.num_constants); o.usize(cm.num_public_inputs);
     o.usize(cm.k_is.size()); for (auto k : cm.k_is) o.usize(canon(k));
     o.usize(cm.num_partial_products);
-    o.usize(0); o.usize(0); o.usize(0);
+    o.usize(cm.num_lookup_polys); o.usize(cm.num_lookup_selectors); o.usize(cm.luts.size());       // mod.rs:1776-1782
+    for (auto& lut : cm.luts) sink_lut(o, lut);
 }
 }
 // kind 0: CommonCircuitData, kind 1: VerifierCircuitData (verifier_only || common).  Returns the size; writes when cap suffices.
@@ -321,6 +328,17 @@ void orc_circuit_info(const void* c, u64* out) {
                  cm.selectors.num_selectors(), cm.fri_reduction_arity_bits.size(), cm.final_poly_len(), cd->pi_row, cd->constant_wires.empty() ? 0 : cd->constant_wires[0].row,
                  cd->arith_ops.size(), cd->poseidon_rows.size()};
     memcpy(out, v, sizeof v);
+}
+// lookup data of a circuit: out6 = [num_lookup_polys, num_lookup_selectors, last_lu_row, last_lut_row, first_lut_row, lut_len]; lut (may be
+// null) receives the (input, output) pairs of the one table
+void orc_circuit_lookup_info(const void* c, u64* out6, uint16_t* lut) {
+    const CircuitData* cd = (const CircuitData*)c;
+    const CommonData& cm = cd->common;
+    u64 v[6] = {cm.num_lookup_polys, cm.num_lookup_selectors, 0, 0, 0, cm.luts.empty() ? 0 : cm.luts[0].size()};
+    if (!cd->lookup_rows.empty()) { v[2] = cd->lookup_rows[0].last_lu_gate; v[3] = cd->lookup_rows[0].last_lut_gate; v[4] = cd->lookup_rows[0].first_lut_gate; }
+    else if (!cm.luts.empty()) v[3] = cm.last_lut_row;
+    memcpy(out6, v, sizeof v);
+    if (lut && !cm.luts.empty()) for (size_t i = 0; i < cm.luts[0].size(); i++) { lut[2 * i] = cm.luts[0][i].first; lut[2 * i + 1] = cm.luts[0][i].second; }
 }
 void orc_circuit_digest(const void* c, u64* out4) { for (int i = 0; i < 4; i++) out4[i] = canon(((const CircuitData*)c)->circuit_digest.e[i]); }
 void orc_circuit_cs_cap(const void* c, u64* out) { write_digests(((const CircuitData*)c)->constants_sigmas_commitment.tree.cap(), out); }

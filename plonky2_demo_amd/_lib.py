@@ -150,6 +150,8 @@ class CircuitDesc(ctypes.Structure):
         ("num_fri_rounds", c_u32), ("fri_arity_bits", c_u32 * 8), ("num_public_inputs", c_u32), ("num_gates", c_u32),
         ("gate_types", ctypes.c_uint8 * 8), ("gate_selector_index", c_u32 * 8),
         ("gate_group_start", c_u32 * 8), ("gate_group_end", c_u32 * 8), ("k_is", c_u64 * 80),
+        ("num_lookup_polys", c_u32), ("num_lookup_selectors", c_u32), ("last_lu_row", c_u32), ("last_lut_row", c_u32), ("first_lut_row", c_u32),
+        ("lut_len", c_u32), ("lut", ctypes.c_uint16 * 2048),
     ]
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -114,13 +114,22 @@ static int validate_desc(const gl_circuit_desc& d) {
                "only standard_recursion_config (135 wires, 80 routed, 2 challenges, quotient factor 8) is supported");
     GL_REQUIRE(d.rate_bits == 3, GL_ERR_UNSUPPORTED, "rate_bits must equal log2(quotient_degree_factor) = 3 (prover.rs:596-608 step = 1)");
     GL_REQUIRE(d.cap_height <= d.degree_bits + d.rate_bits && d.degree_bits >= 1 && d.degree_bits + d.rate_bits <= 24, GL_ERR_ARG, "bad degree / cap height");
-    GL_REQUIRE(d.num_gates >= 1 && d.num_gates <= 8 && d.num_selectors >= 1 && d.num_selectors <= 4 && d.num_constants == d.num_selectors + 2, GL_ERR_ARG, "bad gate / selector description");
+    GL_REQUIRE((d.num_lookup_polys == 0 && d.num_lookup_selectors == 0 && d.lut_len == 0) ||
+               (d.num_lookup_polys == 7 && d.num_lookup_selectors == 5 && d.lut_len >= 1 && d.lut_len <= GL_MAX_LUT_ENTRIES), GL_ERR_UNSUPPORTED,
+               "lookups: one table of at most 1024 entries, 7 lookup polynomials and 5 lookup selectors per challenge");
+    if (d.lut_len) {
+        const uint32_t nrows = 1u << d.degree_bits, lut_rows = (d.lut_len + glhost::LOOKUP_TABLE_SLOTS - 1) / glhost::LOOKUP_TABLE_SLOTS;
+        GL_REQUIRE(d.last_lu_row < d.last_lut_row && d.last_lut_row <= d.first_lut_row && d.first_lut_row + 1 < nrows &&
+                   d.first_lut_row - d.last_lut_row + 1 == lut_rows, GL_ERR_ARG, "bad lookup rows");
+    }
+    GL_REQUIRE(d.num_gates >= 1 && d.num_gates <= 8 && d.num_selectors >= 1 && d.num_selectors <= 4 && d.num_constants == d.num_selectors + d.num_lookup_selectors + 2, GL_ERR_ARG, "bad gate / selector description");
     GL_REQUIRE(d.num_fri_rounds <= 8 && d.num_query_rounds >= 1 && d.num_query_rounds <= 256 && d.proof_of_work_bits <= 40, GL_ERR_ARG, "bad FRI parameters");
     unsigned tot = 0;
     for (unsigned r = 0; r < d.num_fri_rounds; r++) { GL_REQUIRE(d.fri_arity_bits[r] == 4, GL_ERR_UNSUPPORTED, "FRI arity must be 16"); tot += 4; }
     GL_REQUIRE(tot <= d.degree_bits && d.degree_bits + d.rate_bits >= tot + d.cap_height, GL_ERR_ARG, "FRI total reduction arity is too large");   // circuit_builder.rs:977-980
     for (unsigned g = 0; g < d.num_gates; g++) {
-        GL_REQUIRE(d.gate_types[g] <= glhost::G_BASE_SUM, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>}");
+        GL_REQUIRE(d.gate_types[g] <= glhost::G_LOOKUP_TABLE, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable}");
+        GL_REQUIRE((d.gate_types[g] != glhost::G_LOOKUP && d.gate_types[g] != glhost::G_LOOKUP_TABLE) || d.lut_len, GL_ERR_ARG, "lookup gates without a lookup table");
         GL_REQUIRE(d.gate_selector_index[g] < d.num_selectors && d.gate_group_start[g] <= g && g < d.gate_group_end[g] && d.gate_group_end[g] <= d.num_gates, GL_ERR_ARG, "bad selector group");
     }
     return GL_OK;

@@ -16,7 +16,8 @@
 
 namespace {
 // position of each gate type in DefaultGateSerializer's list (gate_serialization.rs:89-107)
-const uint32_t TAG_ARITHMETIC = 0, TAG_BASE_SUM_2 = 2, TAG_CONSTANT = 3, TAG_NOOP = 9, TAG_POSEIDON = 11, TAG_PUBLIC_INPUT = 12;
+const uint32_t TAG_ARITHMETIC = 0, TAG_BASE_SUM_2 = 2, TAG_CONSTANT = 3, TAG_LOOKUP = 6, TAG_LOOKUP_TABLE = 7, TAG_NOOP = 9, TAG_POSEIDON = 11, TAG_PUBLIC_INPUT = 12;
+const uint64_t LOOKUP_SLOTS = 40, LOOKUP_TABLE_SLOTS = 26;     // gates/lookup.rs:41-44, gates/lookup_table.rs:47-50
 const uint64_t BASE_SUM_LIMBS = 63;     // BaseSumGate::<2>::new_from_config under standard_recursion_config (gates/base_sum.rs:31-35)
 // standard_recursion_config (plonk/circuit_data.rs:72-90)
 const uint64_t STD_SECURITY_BITS = 100, STD_CONFIG_NUM_CONSTANTS = 2, STD_FINAL_POLY_BITS = 5, STD_ARITY_BITS = 4;
@@ -27,6 +28,8 @@ struct Writer {
     void u32(uint32_t x) { for (int i = 0; i < 4; i++) b.push_back((uint8_t)(x >> (8 * i))); }
     void u64(uint64_t x) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(x >> (8 * i))); }       // write_usize (mod.rs:1220-1222)
     void field(gl_t x) { u64(gl_canon(x)); }                                                          // write_field (mod.rs:1237-1242)
+    void u16(uint16_t x) { b.push_back((uint8_t)x); b.push_back((uint8_t)(x >> 8)); }
+    void lut(const gl_circuit_desc& d) { u64(d.lut_len); for (uint32_t i = 0; i < 2 * d.lut_len; i++) u16(d.lut[i]); }      // write_lut (mod.rs:2077-2085)
 };
 struct Reader {
     const uint8_t* p; size_t n, pos = 0; bool ok = true;
@@ -34,6 +37,7 @@ struct Reader {
     uint64_t take(int k) { if (!ok || n - pos < (size_t)k) { ok = false; return 0; } uint64_t v = 0; for (int i = 0; i < k; i++) v |= (uint64_t)p[pos + i] << (8 * i); pos += k; return v; }
     uint8_t u8() { return (uint8_t)take(1); }
     uint32_t u32() { return (uint32_t)take(4); }
+    uint16_t u16() { return (uint16_t)take(2); }
     uint64_t u64() { return take(8); }
     // a `usize` that this library keeps in 32 bits: anything larger is a file this library cannot represent, never a narrowing
     // (2^32 + 135 must not read as 135)
@@ -42,10 +46,10 @@ struct Reader {
 };
 
 uint32_t gate_tag(uint8_t type) {
-    switch (type) { case 0: return TAG_NOOP; case 1: return TAG_CONSTANT; case 2: return TAG_PUBLIC_INPUT; case 3: return TAG_ARITHMETIC; case 5: return TAG_BASE_SUM_2; default: return TAG_POSEIDON; }
+    switch (type) { case 0: return TAG_NOOP; case 1: return TAG_CONSTANT; case 2: return TAG_PUBLIC_INPUT; case 3: return TAG_ARITHMETIC; case 5: return TAG_BASE_SUM_2; case 6: return TAG_LOOKUP; case 7: return TAG_LOOKUP_TABLE; default: return TAG_POSEIDON; }
 }
 uint64_t gate_constraints(uint8_t type, const gl_circuit_desc& d) {
-    switch (type) { case 0: return 0; case 1: return d.num_constants - d.num_selectors; case 2: return 4; case 3: return d.num_routed_wires / 4; case 5: return 1 + BASE_SUM_LIMBS /* gates/base_sum.rs:144-146 */; default: return 123; }   // gates/poseidon.rs:403-409
+    switch (type) { case 0: case 6: case 7: return 0; case 1: return d.num_constants - d.num_selectors - d.num_lookup_selectors; case 2: return 4; case 3: return d.num_routed_wires / 4; case 5: return 1 + BASE_SUM_LIMBS /* gates/base_sum.rs:144-146 */; default: return 123; }   // gates/poseidon.rs:403-409
 }
 void write_fri_config(Writer& w, const gl_circuit_desc& d) {          // mod.rs:1628-1644
     w.u64(d.rate_bits); w.u64(d.cap_height); w.u64(d.num_query_rounds); w.u32(d.proof_of_work_bits);
@@ -73,7 +77,8 @@ extern "C" int gl_common_data_to_bytes(const gl_circuit_desc* desc, uint8_t* h_o
     // everything the writer indexes or divides by (k_is holds 80 entries)
     GL_REQUIRE(d.num_routed_wires >= 4 && d.num_routed_wires <= 80 && d.quotient_degree_factor >= 1 && d.num_constants >= d.num_selectors, GL_ERR_ARG,
                "bad circuit description: routed wires 4..80, quotient degree factor >= 1, constants >= selectors");
-    for (uint32_t g = 0; g < d.num_gates; g++) GL_REQUIRE(d.gate_types[g] <= 5, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>}");
+    for (uint32_t g = 0; g < d.num_gates; g++) GL_REQUIRE(d.gate_types[g] <= 7, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable}");
+    GL_REQUIRE(d.lut_len <= GL_MAX_LUT_ENTRIES && d.num_constants >= d.num_selectors + d.num_lookup_selectors, GL_ERR_ARG, "bad lookup description");
     Writer w;
     // CircuitConfig (mod.rs:1662-1686)
     w.u64(d.num_wires); w.u64(d.num_routed_wires); w.u64(STD_CONFIG_NUM_CONSTANTS); w.u64(STD_SECURITY_BITS); w.u64(d.num_challenges);
@@ -89,7 +94,9 @@ extern "C" int gl_common_data_to_bytes(const gl_circuit_desc* desc, uint8_t* h_o
     for (uint32_t g = 0; g < d.num_gates; g++) {
         w.u32(gate_tag(d.gate_types[g]));
         if (d.gate_types[g] == 3) w.u64(d.num_routed_wires / 4);                   // ArithmeticGate { num_ops }
-        if (d.gate_types[g] == 1) w.u64(d.num_constants - d.num_selectors);        // ConstantGate { num_consts }
+        if (d.gate_types[g] == 1) w.u64(d.num_constants - d.num_selectors - d.num_lookup_selectors);      // ConstantGate { num_consts }
+        if (d.gate_types[g] == 6) { w.u64(LOOKUP_SLOTS); w.lut(d); }                // LookupGate { num_slots, lut } (gates/lookup.rs:59-62)
+        if (d.gate_types[g] == 7) { w.u64(LOOKUP_TABLE_SLOTS); w.lut(d); w.u64(d.last_lut_row); }      // LookupTableGate (gates/lookup_table.rs:70-74)
         if (d.gate_types[g] == 5) w.u64(BASE_SUM_LIMBS);                           // BaseSumGate<2> { num_limbs } (gates/base_sum.rs:53-55)
         const uint64_t c = gate_constraints(d.gate_types[g], d);
         if (c > max_constraints) max_constraints = c;
@@ -105,7 +112,8 @@ extern "C" int gl_common_data_to_bytes(const gl_circuit_desc* desc, uint8_t* h_o
     w.u64(d.quotient_degree_factor); w.u64(max_constraints); w.u64(d.num_constants); w.u64(d.num_public_inputs);
     w.u64(d.num_routed_wires); for (uint32_t j = 0; j < d.num_routed_wires; j++) w.field(d.k_is[j]);
     w.u64((d.num_routed_wires + d.quotient_degree_factor - 1) / d.quotient_degree_factor - 1);      // num_partial_products (circuit_builder.rs, util/partial_products.rs:40-47)
-    w.u64(0); w.u64(0); w.u64(0);                                                  // no lookup polynomials, selectors, tables
+    w.u64(d.num_lookup_polys); w.u64(d.num_lookup_selectors);                      // mod.rs:1776-1782
+    w.u64(d.lut_len ? 1 : 0); if (d.lut_len) w.lut(d);                             // luts: at most the one table
     *num_bytes = w.b.size();
     if (!h_out) return GL_OK;
     GL_REQUIRE(cap >= w.b.size(), GL_ERR_ARG, "gl_common_data_to_bytes: output too small");
@@ -144,7 +152,8 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
     const uint64_t ngates = r.u64();
     GL_REQUIRE(r.ok && ngates >= 1 && ngates <= 8, GL_ERR_UNSUPPORTED, "1..8 gate types");
     d.num_gates = (uint32_t)ngates;
-    uint64_t arith_ops = 0, const_consts = 0;
+    uint64_t arith_ops = 0, const_consts = 0, gate_lut_len = 0;
+    bool lut_differs = false;
     for (uint64_t g = 0; g < ngates; g++) {
         const uint32_t tag = r.u32();
         if (tag == TAG_NOOP) d.gate_types[g] = 0;
@@ -157,7 +166,17 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
             const uint64_t limbs = r.u64();
             GL_REQUIRE(!r.ok || limbs == BASE_SUM_LIMBS, GL_ERR_UNSUPPORTED, "BaseSumGate<2> with a limb count other than new_from_config's 63");
         }
-        else return gl_fail(GL_ERR_UNSUPPORTED, "gate outside {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>}", __FILE__, __LINE__);
+        else if (tag == TAG_LOOKUP || tag == TAG_LOOKUP_TABLE) {
+            d.gate_types[g] = tag == TAG_LOOKUP ? 6 : 7;
+            const uint64_t slots = r.u64(), len = r.u64();
+            GL_REQUIRE(!r.ok || (slots == (tag == TAG_LOOKUP ? LOOKUP_SLOTS : LOOKUP_TABLE_SLOTS) && len >= 1 && len <= GL_MAX_LUT_ENTRIES), GL_ERR_UNSUPPORTED,
+                       "lookup gate: slot count of standard_recursion_config and a table of at most 1024 entries");
+            GL_REQUIRE(!r.ok || !gate_lut_len || gate_lut_len == len, GL_ERR_UNSUPPORTED, "more than one lookup table");
+            for (uint64_t k = 0; k < 2 * len && r.ok; k++) { const uint16_t v = r.u16(); if (gate_lut_len && d.lut[k] != v) lut_differs = true; d.lut[k] = v; }
+            gate_lut_len = len;
+            if (tag == TAG_LOOKUP_TABLE) d.last_lut_row = r.usize32();
+        }
+        else return gl_fail(GL_ERR_UNSUPPORTED, "gate outside {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable}", __FILE__, __LINE__);
     }
     const uint64_t nsel = r.u64();
     GL_REQUIRE(r.ok && nsel == ngates, GL_ERR_ARG, "selector_indices length differs from the number of gates");
@@ -181,8 +200,20 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
     const uint64_t nlp = r.u64(), nls = r.u64(), nluts = r.u64();
     GL_REQUIRE(!r.wide, GL_ERR_UNSUPPORTED, "a size field of CommonCircuitData exceeds 32 bits");
     GL_REQUIRE(r.ok, GL_ERR_ARG, "truncated CommonCircuitData");
-    GL_REQUIRE(nlp == 0 && nls == 0 && nluts == 0, GL_ERR_UNSUPPORTED, "lookup arguments are not supported");
-    GL_REQUIRE(max_qdf == d.quotient_degree_factor && cfg_consts + d.num_selectors == d.num_constants, GL_ERR_UNSUPPORTED, "constants / quotient degree layout");
+    GL_REQUIRE(nluts <= 1 && ((nluts == 0 && nlp == 0 && nls == 0 && !gate_lut_len) || (nluts == 1 && nlp == 7 && nls == 5 && gate_lut_len)), GL_ERR_UNSUPPORTED,
+               "lookup argument: one table, 7 lookup polynomials and 5 lookup selectors per challenge");
+    if (nluts) {
+        const uint64_t len = r.u64();
+        GL_REQUIRE(r.ok && len == gate_lut_len, GL_ERR_ARG, "the lookup table of CommonCircuitData differs from the lookup gates'");
+        for (uint64_t k = 0; k < 2 * len && r.ok; k++) if (r.u16() != d.lut[k]) lut_differs = true;
+        GL_REQUIRE(r.ok, GL_ERR_ARG, "truncated CommonCircuitData");
+        GL_REQUIRE(!lut_differs, GL_ERR_ARG, "the lookup table of CommonCircuitData differs from the lookup gates'");
+        d.lut_len = (uint32_t)len; d.num_lookup_polys = (uint32_t)nlp; d.num_lookup_selectors = (uint32_t)nls;
+        // LookupWire is prover data (circuit_data.rs:296-299), not part of these bytes: last_lu_row / first_lut_row are derived from the
+        // LookupTableGate's last_lut_row and the table length; last_lu_row is unknown here and left 0 (the verifier does not need it)
+        d.first_lut_row = d.last_lut_row + (uint32_t)((len + LOOKUP_TABLE_SLOTS - 1) / LOOKUP_TABLE_SLOTS) - 1;
+    }
+    GL_REQUIRE(max_qdf == d.quotient_degree_factor && cfg_consts + d.num_selectors + d.num_lookup_selectors == d.num_constants, GL_ERR_UNSUPPORTED, "constants / quotient degree layout");
     GL_REQUIRE((!arith_ops || arith_ops == d.num_routed_wires / 4) && (!const_consts || const_consts == cfg_consts), GL_ERR_UNSUPPORTED, "gate parameters");
     *out = d;
     if (consumed) *consumed = r.pos;

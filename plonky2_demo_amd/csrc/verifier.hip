@@ -144,11 +144,14 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
     const gl_circuit_desc& d = *desc;
     GL_REQUIRE(d.num_wires == 135 && d.num_routed_wires == 80 && d.num_challenges == 2 && d.quotient_degree_factor == 8 && d.rate_bits == 3,
                GL_ERR_UNSUPPORTED, "gl_verify: only standard_recursion_config circuits are supported");
-    GL_REQUIRE(d.num_gates >= 1 && d.num_gates <= 8 && d.num_selectors >= 1 && d.num_constants == d.num_selectors + 2 && d.num_fri_rounds <= 8 &&
+    GL_REQUIRE((d.num_lookup_polys == 0 && d.num_lookup_selectors == 0 && d.lut_len == 0) ||
+               (d.num_lookup_polys == 7 && d.num_lookup_selectors == 5 && d.lut_len >= 1 && d.lut_len <= GL_MAX_LUT_ENTRIES), GL_ERR_UNSUPPORTED,
+               "gl_verify: lookups: one table of at most 1024 entries, 7 lookup polynomials and 5 lookup selectors per challenge");
+    GL_REQUIRE(d.num_gates >= 1 && d.num_gates <= 8 && d.num_selectors >= 1 && d.num_constants == d.num_selectors + d.num_lookup_selectors + 2 && d.num_fri_rounds <= 8 &&
                d.degree_bits >= 1 && d.degree_bits + d.rate_bits <= 32 && d.cap_height <= d.degree_bits + d.rate_bits && d.num_query_rounds >= 1,
                GL_ERR_ARG, "gl_verify: bad circuit description");
     for (unsigned g = 0; g < d.num_gates; g++)
-        GL_REQUIRE(d.gate_types[g] <= glhost::G_BASE_SUM && d.gate_selector_index[g] < d.num_selectors && d.gate_group_start[g] <= g && g < d.gate_group_end[g] && d.gate_group_end[g] <= d.num_gates,
+        GL_REQUIRE(d.gate_types[g] <= glhost::G_LOOKUP_TABLE && d.gate_selector_index[g] < d.num_selectors && d.gate_group_start[g] <= g && g < d.gate_group_end[g] && d.gate_group_end[g] <= d.num_gates,
                    GL_ERR_ARG, "gl_verify: bad gate / selector description");
     const size_t nch = 2, R = 80, W = 135, QF = 8, NPP = 9;            // partial products per challenge: ceil(80 / 8) - 1
     const size_t ncap = size_t(1) << d.cap_height, ncs = d.num_constants + R;
@@ -158,7 +161,9 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
     for (unsigned r = 0; r < d.num_fri_rounds; r++) { GL_REQUIRE(d.fri_arity_bits[r] >= 1 && d.fri_arity_bits[r] <= 8, GL_ERR_ARG, "gl_verify: bad FRI arity"); total_arity += d.fri_arity_bits[r]; }
     GL_REQUIRE(total_arity <= lgn, GL_ERR_ARG, "gl_verify: FRI reduces below the final polynomial");
     const size_t final_len = size_t(1) << (lgn - total_arity);
-    const size_t widths[4] = {ncs, W, nch * (1 + NPP), nch * QF};
+    const size_t NLP = d.num_lookup_polys;                              // lookup polynomials per challenge, behind Z and the partial products
+    const size_t nzp = nch * (1 + NPP);
+    const size_t widths[4] = {ncs, W, nzp + nch * NLP, nch * QF};
 
     // ---- decode (util/serialization/mod.rs:1939-1981 read side, plonk/validate_shape.rs, fri/validate_shape.rs) ----
     // like the reference's read_field (from_canonical_u64 without a range check in release builds) a word >= p is taken mod p
@@ -168,8 +173,9 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
     auto words = [&](size_t k) { size_t at = T.size(); for (size_t i = 0; i < k && in.ok; i++) T.push_back(gl_canon(in.u64())); return at; };
     struct PathRef { size_t leaf, leaf_len, sib, nsib; };
     const size_t o_caps = words(3 * 4 * ncap);
+    // OpeningSet in wire order (mod.rs:1409-1423): the lookup vectors sit between zs_next and the partial products
     const size_t o_const = words(2 * d.num_constants), o_sig = words(2 * R), o_wires = words(2 * W), o_zs = words(2 * nch), o_zsn = words(2 * nch),
-                 o_pp = words(2 * nch * NPP), o_quot = words(2 * nch * QF);
+                 o_lk = words(2 * nch * NLP), o_lkn = words(2 * nch * NLP), o_pp = words(2 * nch * NPP), o_quot = words(2 * nch * QF);
     const size_t o_fcaps = words((size_t)d.num_fri_rounds * 4 * ncap);
     std::vector<PathRef> init_paths((size_t)d.num_query_rounds * 4), step_paths((size_t)d.num_query_rounds * d.num_fri_rounds);
     for (unsigned q = 0; q < d.num_query_rounds && in.ok; q++) {
@@ -206,14 +212,17 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
     gl_t betas[2], gammas[2], alphas[2];
     for (auto& b : betas) b = tr.draw();
     for (auto& g : gammas) g = tr.draw();
+    // lookup coins (get_challenges.rs:51-63): [betas | gammas | 4 more], four per challenge
+    gl_t deltas[8] = {betas[0], betas[1], gammas[0], gammas[1], 0, 0, 0, 0};
+    if (NLP) for (int i = 4; i < 8; i++) deltas[i] = tr.draw();
     tr.absorb(&T[o_caps + 4 * ncap], 4 * ncap);
     for (auto& a : alphas) a = tr.draw();
     tr.absorb(&T[o_caps + 8 * ncap], 4 * ncap);
     const E zeta = tr.draw_ext();
     // FriOpenings (plonk/proof.rs:346-380): constants, sigmas, wires, zs, partial products, quotient at zeta; zs_next at g zeta
     tr.absorb(&T[o_const], 2 * d.num_constants); tr.absorb(&T[o_sig], 2 * R); tr.absorb(&T[o_wires], 2 * W); tr.absorb(&T[o_zs], 2 * nch);
-    tr.absorb(&T[o_pp], 2 * nch * NPP); tr.absorb(&T[o_quot], 2 * nch * QF);
-    tr.absorb(&T[o_zsn], 2 * nch);
+    tr.absorb(&T[o_pp], 2 * nch * NPP); tr.absorb(&T[o_quot], 2 * nch * QF); tr.absorb(&T[o_lk], 2 * nch * NLP);
+    tr.absorb(&T[o_zsn], 2 * nch); tr.absorb(&T[o_lkn], 2 * nch * NLP);
     const E fri_alpha = tr.draw_ext();
     E fri_betas[8];
     for (unsigned r = 0; r < d.num_fri_rounds; r++) { tr.absorb(&T[o_fcaps + (size_t)r * 4 * ncap], 4 * ncap); fri_betas[r] = tr.draw_ext(); }
@@ -234,7 +243,7 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
         // gate constraints, summed slot-wise with each gate's selector filter (vanishing_poly.rs:671-699, gate.rs:277-284)
         const size_t NGC = 123;
         std::vector<E> gate_terms(NGC, e_of(0));
-        const E* gate_consts = consts.data() + d.num_selectors;
+        const E* gate_consts = consts.data() + d.num_selectors + d.num_lookup_selectors;      // gate.rs:129-133
         E tmp[123];
         for (unsigned g = 0; g < d.num_gates; g++) {
             const E sel = consts[d.gate_selector_index[g]];
@@ -243,7 +252,7 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
             if (d.num_selectors > 1) filter = e_mul(filter, e_sub(e_of(glhost::UNUSED_SELECTOR), sel));
             size_t cnt = 0;
             switch (d.gate_types[g]) {
-                case glhost::G_NOOP: break;
+                case glhost::G_NOOP: case glhost::G_LOOKUP: case glhost::G_LOOKUP_TABLE: break;          // no main-trace constraints (lookup.rs:72-75)
                 case glhost::G_CONSTANT: cnt = 2; for (int i = 0; i < 2; i++) tmp[i] = e_sub(gate_consts[i], wires[i]); break;                        // constant.rs:59-66
                 case glhost::G_PUBLIC_INPUT: cnt = 4; for (int i = 0; i < 4; i++) tmp[i] = e_sub(wires[i], e_of(pi_hash[i])); break;                     // public_input.rs:44-49
                 case glhost::G_ARITHMETIC: cnt = 20;                                                                                                    // arithmetic_base.rs:72-92
@@ -282,6 +291,49 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
                     terms.push_back(e_sub(e_mul(prev, np), e_mul(next, dp)));
                 }
             }
+            // lookup constraints of every challenge (vanishing_poly.rs:263-281, 337-500)
+            for (size_t i = 0; i < nch && NLP; i++) {
+                const gl_t* dl = deltas + glhost::NUM_COINS_LOOKUP * i;
+                const size_t num_sldc = NLP - 1, lu_degree = QF - 1, lut_degree = (glhost::LOOKUP_TABLE_SLOTS + num_sldc - 1) / num_sldc;
+                const E* sel = consts.data() + d.num_selectors;
+                auto zx = [&](size_t k) { return ext_at(o_lk, i * NLP + 1 + k); };
+                auto zgx = [&](size_t k) { return ext_at(o_lkn, i * NLP + 1 + k); };
+                const E z_re = ext_at(o_lk, i * NLP), next_z_re = ext_at(o_lkn, i * NLP);
+                E looked[glhost::LOOKUP_TABLE_SLOTS], combo[glhost::LOOKUP_TABLE_SLOTS], looking[glhost::LOOKUP_SLOTS];
+                for (int sl = 0; sl < glhost::LOOKUP_TABLE_SLOTS; sl++) {
+                    looked[sl] = e_add(wires[3 * sl], e_scale(wires[3 * sl + 1], dl[glhost::LU_CH_A]));
+                    combo[sl] = e_add(wires[3 * sl], e_scale(wires[3 * sl + 1], dl[glhost::LU_CH_B]));
+                }
+                for (int sl = 0; sl < glhost::LOOKUP_SLOTS; sl++) looking[sl] = e_add(wires[2 * sl], e_scale(wires[2 * sl + 1], dl[glhost::LU_CH_A]));
+                terms.push_back(e_mul(sel[glhost::LU_SEL_LAST_LDC], zx(num_sldc - 1)));
+                terms.push_back(e_mul(sel[glhost::LU_SEL_INIT_SRE], zx(0)));
+                terms.push_back(e_mul(sel[glhost::LU_SEL_INIT_SRE], z_re));
+                {   // final RE: the table's polynomial at delta (get_lut_poly, vanishing_poly.rs:31-49): combos zero-padded to whole rows, reversed
+                    const size_t rows = (d.lut_len + glhost::LOOKUP_TABLE_SLOTS - 1) / glhost::LOOKUP_TABLE_SLOTS, deg = rows * glhost::LOOKUP_TABLE_SLOTS;
+                    gl_t f = 0;
+                    for (size_t k = 0; k < deg; k++) {
+                        const gl_t c = k < d.lut_len ? gl_add((gl_t)d.lut[2 * k], gl_mul(dl[glhost::LU_CH_B], (gl_t)d.lut[2 * k + 1])) : 0;
+                        f = gl_add(gl_mul(f, dl[glhost::LU_CH_DELTA]), c);
+                    }
+                    terms.push_back(e_mul(sel[glhost::LU_SEL_START_END], e_sub(z_re, e_of(gl_canon(f)))));
+                }
+                E cur = next_z_re;
+                for (int sl = 0; sl < glhost::LOOKUP_TABLE_SLOTS; sl++) cur = e_add(e_scale(cur, dl[glhost::LU_CH_DELTA]), combo[sl]);
+                terms.push_back(e_mul(sel[glhost::LU_SEL_TRANS_SRE], e_sub(z_re, cur)));
+                const E al = e_of(dl[glhost::LU_CH_ALPHA]);
+                for (size_t poly = 0; poly < num_sldc; poly++) {
+                    const size_t t0 = poly * lut_degree, t1 = std::min<size_t>((poly + 1) * lut_degree, glhost::LOOKUP_TABLE_SLOTS);
+                    const size_t u0 = poly * lu_degree, u1 = std::min<size_t>((poly + 1) * lu_degree, glhost::LOOKUP_SLOTS);
+                    E lut_prod = e_of(1), lu_prod = e_of(1), lu_sum = e_of(0), lut_sum_mul = e_of(0);
+                    for (size_t a = t0; a < t1; a++) lut_prod = e_mul(lut_prod, e_sub(al, looked[a]));
+                    for (size_t a = u0; a < u1; a++) lu_prod = e_mul(lu_prod, e_sub(al, looking[a]));
+                    for (size_t a = u0; a < u1; a++) { E pr = e_of(1); for (size_t b = u0; b < u1; b++) if (b != a) pr = e_mul(pr, e_sub(al, looking[b])); lu_sum = e_add(lu_sum, pr); }
+                    for (size_t a = t0; a < t1; a++) { E pr = e_of(1); for (size_t b = t0; b < t1; b++) if (b != a) pr = e_mul(pr, e_sub(al, looked[b])); lut_sum_mul = e_add(lut_sum_mul, e_mul(wires[3 * a + 2], pr)); }
+                    const E prev = poly == 0 ? zgx(num_sldc - 1) : zx(poly - 1);
+                    terms.push_back(e_mul(sel[glhost::LU_SEL_TRANS_SRE], e_sub(e_mul(lut_prod, e_sub(zx(poly), prev)), lut_sum_mul)));
+                    terms.push_back(e_mul(sel[glhost::LU_SEL_TRANS_LDC], e_add(e_mul(lu_prod, e_sub(zx(poly), prev)), lu_sum)));
+                }
+            }
             terms.insert(terms.end(), gate_terms.begin(), gate_terms.end());
             E acc = e_of(0);                                                      // reduce_with_powers (plonk_common.rs:97-128)
             for (size_t t = terms.size(); t-- > 0;) acc = e_add(terms[t], e_scale(acc, alphas[c]));
@@ -303,7 +355,9 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
     for (size_t i = 0; i < nch; i++) open0.push_back(ext_at(o_zs, i));
     for (size_t i = 0; i < nch * NPP; i++) open0.push_back(ext_at(o_pp, i));
     for (size_t i = 0; i < nch * QF; i++) open0.push_back(ext_at(o_quot, i));
+    for (size_t i = 0; i < nch * NLP; i++) open0.push_back(ext_at(o_lk, i));          // lookup polynomials come last in both batches (circuit_data.rs:564-597)
     for (size_t i = 0; i < nch; i++) open1.push_back(ext_at(o_zsn, i));
+    for (size_t i = 0; i < nch * NLP; i++) open1.push_back(ext_at(o_lkn, i));
     const E red0 = horner(open0), red1 = horner(open1);
     E alpha_shift = e_of(1);
     for (size_t i = 0; i < open1.size(); i++) alpha_shift = e_mul(alpha_shift, fri_alpha);
@@ -322,8 +376,10 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
         gl_t subgroup_x = gl_canon(gl_mul(GL_MULT_GENERATOR, gl_exp(wN, rev)));
         // fri_combine_initial (fri/verifier.rs:124-165): batch 0 = every polynomial at zeta, batch 1 = the Z polynomials at g zeta
         ev0.clear(); ev1.clear();
-        for (int o = 0; o < 4; o++) { const PathRef& pr = init_paths[q * 4 + o]; for (size_t i = 0; i < pr.leaf_len; i++) ev0.push_back(e_of(T[pr.leaf + i])); }
+        for (int o = 0; o < 4; o++) { const PathRef& pr = init_paths[q * 4 + o]; for (size_t i = 0; i < (o == 2 ? nzp : pr.leaf_len); i++) ev0.push_back(e_of(T[pr.leaf + i])); }
+        for (size_t i = nzp; i < widths[2]; i++) ev0.push_back(e_of(T[init_paths[q * 4 + 2].leaf + i]));
         for (size_t i = 0; i < nch; i++) ev1.push_back(e_of(T[init_paths[q * 4 + 2].leaf + i]));
+        for (size_t i = nzp; i < widths[2]; i++) ev1.push_back(e_of(T[init_paths[q * 4 + 2].leaf + i]));
         const E sx = e_of(subgroup_x);
         E eval = e_mul(e_sub(horner(ev0), red0), gl2_inv(e_sub(sx, zeta)));
         eval = e_add(e_mul(eval, alpha_shift), e_mul(e_sub(horner(ev1), red1), gl2_inv(e_sub(sx, gzeta))));

@@ -303,6 +303,12 @@ class OracleCircuit:
         lib.orc_circuit_k_is(self.h, _p(k))
         for j in range(80):
             d.k_is[j] = int(k[j])
+        li = np.zeros(6, dtype=np.uint64)
+        lut = np.zeros(2048, dtype=np.uint16)
+        lib.orc_circuit_lookup_info(self.h, _p(li), lut.ctypes.data_as(ctypes.c_void_p))
+        d.num_lookup_polys, d.num_lookup_selectors, d.last_lu_row, d.last_lut_row, d.first_lut_row, d.lut_len = [int(x) for x in li]
+        for j in range(2 * d.lut_len):
+            d.lut[j] = int(lut[j])
         return d
 
     @property

@@ -176,7 +176,7 @@ def test_common_data_reader_rejects_what_the_library_cannot_prove(orc):
     bad = bytearray(good); bad[6 * 8 + 1] = 1                                      # zero_knowledge = true
     with pytest.raises(p.Plonky2Mi355xError):
         api.common_data_from_bytes(bytes(bad))
-    bad = bytearray(good); bad[-8:] = (1).to_bytes(8, "little")                    # one lookup table
+    bad = bytearray(good); bad[-8:] = (1).to_bytes(8, "little")                    # one lookup table, but no lookup gates / polynomials
     with pytest.raises(p.Plonky2Mi355xError):
         api.common_data_from_bytes(bytes(bad))
     for cut in (0, 7, 60, len(good) - 1):
@@ -216,10 +216,14 @@ def test_common_data_writer_validates_its_description():
         with pytest.raises(p.Plonky2Mi355xError):
             api.common_data_to_bytes(d)
     d = copy.copy(hc.desc)
-    d.gate_types[0] = 7
+    d.gate_types[0] = 9                                   # 0..7 are the supported gate types
     with pytest.raises(p.Plonky2Mi355xError) as e:
         api.common_data_to_bytes(d)
     assert e.value.code == 3
+    d = copy.copy(hc.desc)
+    d.lut_len = 2000                                      # beyond GL_MAX_LUT_ENTRIES: must not index past lut[2048]
+    with pytest.raises(p.Plonky2Mi355xError):
+        api.common_data_to_bytes(d)
 
 
 @pytest.mark.parametrize("bits,value", [(6, 42), (70, 2**64 - 2**32 - 5)])
@@ -259,3 +263,49 @@ def test_base_sum_gate_circuits_verify_natively_and_through_the_byte_form(orc, b
     with pytest.raises(p.Plonky2Mi355xError) as e:
         api.common_data_from_bytes(bytes(bad))
     assert e.value.code == 3
+
+
+@pytest.mark.parametrize("kind,param,inputs", [
+    (8, 2, [1, 2]),                                   # lookup_test.rs test_one_lookup: two lookups in a 256-entry table
+    (8, 50, list(range(3, 53))),                      # test_many_lookups: two LookupGate rows, the second padded with the table's first entry
+    (8, 40, [7] * 40),                                # exactly one full LookupGate row (no padding), one entry looked up 40 times
+    (9, 3, [1000, 1037, 1333]),                       # a 10-entry table whose inputs are not their indices
+])
+def test_lookup_argument_circuits_verify_natively_and_through_the_byte_form(orc, kind, param, inputs):
+    # the lookup argument (plonk/prover.rs:425-572, plonk/vanishing_poly.rs:337-670; LookupGate / LookupTableGate, gate types 6 / 7, ONE
+    # table): the oracle proves (its quotient exists: every lookup constraint vanishes on H), its verifier and the product's independently
+    # written gl_verify accept, both give the same verdict on 60 single-bit mutations, the outputs are the table's, and the circuit data
+    # (lookup gates with their table, num_lookup_polys / selectors, luts) equals the oracle writer's bytes and round-trips.  PARITY UNPINNED.
+    import ctypes
+    from plonky2_demo_amd import api
+    from plonky2_demo_amd._lib import lib, GL_OK
+    oc = orc.circuit_of_kind(kind, param, threads=4)
+    w = oc.witness(np.array(inputs, dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=2)
+    pis = [int(x) for x in w.public_inputs()]
+    table = {i: (3 * i * i + 5 * i + 7) % 256 for i in range(256)} if kind == 8 else {1000 + 37 * i: 17 * i * i + 3 for i in range(10)}
+    assert pis[:param] == inputs and pis[param:] == [table[v] for v in inputs]
+    pr = w.prove(threads=4)
+    assert pr.verify()[0]
+    by = pr.to_bytes()
+    desc = oc.product_desc()
+    assert desc.num_lookup_polys == 7 and desc.num_lookup_selectors == 5 and {6, 7} <= set(list(desc.gate_types)[:desc.num_gates])
+    cap, dig = np.ascontiguousarray(oc.constants_sigmas_cap), np.ascontiguousarray(oc.digest)
+    vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+
+    def native(b):
+        buf = np.frombuffer(b, dtype=np.uint8)
+        return lib.gl_verify(ctypes.byref(desc), vp(cap), vp(dig), vp(buf), buf.size) == GL_OK
+    assert native(by), lib.gl_last_error()
+    rng = np.random.default_rng(param)
+    for _ in range(60):
+        bad = bytearray(by)
+        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        assert native(bytes(bad)) == oc.verify_bytes(bytes(bad), cap, dig)[0]
+    common = api.common_data_to_bytes(desc)
+    assert common == oc.data_bytes(0)
+    d2, used = api.common_data_from_bytes(common)
+    assert used == len(common)
+    d2.last_lu_row = desc.last_lu_row                 # LookupWire.last_lu_gate is prover data: not in CommonCircuitData's bytes
+    assert bytes(d2) == bytes(desc)
+    vd = api.verifier_data_to_bytes(desc, cap, dig)
+    assert vd == oc.data_bytes(1) and api.verify_bytes(vd, by) == (True, "")
