@@ -322,7 +322,7 @@ size_t gl_proof_challenges(const gl_proof* p, uint64_t* h_out);
 int gl_proof_caps(const gl_proof* p, uint64_t* h_out /* [3][2^cap_height][4]: wires, zs_pp, quotient */);
 /* the next two need gl_ctx_capture_intermediates(ctx, 1) before proving (two extra device->host copies per proof) */
 int gl_ctx_capture_intermediates(gl_ctx* ctx, int enable);
-int gl_proof_zs_partial_products(const gl_proof* p, uint64_t* h_out /* [20][n] values */);
+int gl_proof_zs_partial_products(const gl_proof* p, uint64_t* h_out /* [20][n] values; [34][n] with lookups: the 14 lookup polynomials follow */);
 int gl_proof_quotient_chunks(const gl_proof* p, uint64_t* h_out /* [16][n] coefficients */);
 size_t gl_proof_query_indices(const gl_proof* p, uint64_t* h_out);
 void gl_proof_free(gl_proof* p);

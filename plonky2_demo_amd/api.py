@@ -854,8 +854,9 @@ class Proof:
         check(lib.gl_proof_caps(self.handle, _p(out)))
         return out
 
-    def zs_partial_products(self):
-        out = np.empty((20, self.n), dtype=np.uint64)
+    def zs_partial_products(self, ncols=20):
+        """Z and partial products as value columns; 34 columns for a circuit with lookups (the lookup polynomials follow)."""
+        out = np.empty((ncols, self.n), dtype=np.uint64)
         check(lib.gl_proof_zs_partial_products(self.handle, _p(out)))
         return out
 

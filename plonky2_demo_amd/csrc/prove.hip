@@ -360,6 +360,24 @@ static int partial_products_values(gl_ctx* ctx, const gl_circuit* cir, const gl_
     GL_CHECK_HIP(hipGetLastError());
     return GL_OK;
 }
+// ---- compute_all_lookup_polys (plonk/prover.rs:425-572): d_out[2 * 7][n] VALUES (RE + 6 partial SLDC per challenge) ----
+static int lookup_polys_values(gl_ctx* ctx, const gl_circuit* cir, const gl_t* d_wires, const gl_t* deltas8, gl_t* d_out) {
+    const gl_circuit_desc& d = cir->desc;
+    const size_t n = cir->n;
+    hipStream_t st = ctx->stream;
+    const uint32_t nrows = d.first_lut_row - d.last_lu_row + 1;
+    DevBuf d_inv(ctx); GL_TRY(d_inv.alloc((size_t)2 * nrows * 64 * sizeof(gl_t)));
+    gl_t dl[8]; for (int i = 0; i < 8; i++) dl[i] = gl_canon(deltas8[i]);
+    ctx->timing_begin("compute lookup polys");
+    GL_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)2 * d.num_lookup_polys * n * sizeof(gl_t), st));
+    hipLaunchKernelGGL(k_lookup_inverses, dim3(nrows, 2), dim3(64), 0, st, d_wires, (uint32_t)n, d.last_lu_row, d.last_lut_row,
+                       dl[glhost::LU_CH_A], dl[glhost::LU_CH_ALPHA], dl[4 + glhost::LU_CH_A], dl[4 + glhost::LU_CH_ALPHA], d_inv.as<gl_t>());
+    hipLaunchKernelGGL(k_lookup_scan, dim3(1), dim3(64), 0, st, d_wires, (uint32_t)n, d.last_lu_row, d.last_lut_row, d.first_lut_row,
+                       dl[glhost::LU_CH_B], dl[glhost::LU_CH_DELTA], dl[4 + glhost::LU_CH_B], dl[4 + glhost::LU_CH_DELTA], d_inv.as<const gl_t>(), d_out);
+    ctx->timing_end();
+    GL_CHECK_HIP(hipGetLastError());
+    return GL_OK;
+}
 static int check_phase_args(gl_ctx* ctx, const gl_circuit* cir) {
     GL_REQUIRE(ctx && cir, GL_ERR_ARG, "null context / circuit");
     GL_REQUIRE(cir->ctx->device == ctx->device, GL_ERR_ARG, "circuit lives on another device");
@@ -372,6 +390,7 @@ static int check_batch(const gl_circuit* cir, const gl_batch* b, size_t ncols, c
 extern "C" int gl_partial_products(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t betas[2], const uint64_t gammas[2], gl_batch** out) {
     GL_TRY(check_phase_args(ctx, cir));
     GL_REQUIRE(d_wires && betas && gammas && out, GL_ERR_ARG, "gl_partial_products: null argument");
+    GL_REQUIRE(!cir->desc.num_lookup_polys, GL_ERR_UNSUPPORTED, "the phase API does not carry the lookup challenges: prove circuits with lookups through gl_prove*");
     DevBuf d_zs(ctx); GL_TRY(d_zs.alloc(20 * cir->n * sizeof(gl_t)));
     GL_TRY(partial_products_values(ctx, cir, d_wires, betas, gammas, d_zs.as<gl_t>()));
     return gl_batch_from_device(ctx, d_zs.as<uint64_t>(), 20, cir->n, cir->desc.rate_bits, cir->desc.cap_height, 1, out);
@@ -379,7 +398,7 @@ extern "C" int gl_partial_products(gl_ctx* ctx, const gl_circuit* cir, const uin
 
 // ---- 9. compute_quotient_polys + split (plonk/prover.rs:229-258,574-744): d_q[2][8n] -> the 16 chunk COEFFICIENT columns ----
 static int quotient_chunks(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* wires, const gl_batch* zs, const gl_t* pi_hash,
-                           const gl_t* betas, const gl_t* gammas, const gl_t* alphas, gl_t* d_q, std::vector<gl_t>& apow) {
+                           const gl_t* betas, const gl_t* gammas, const gl_t* alphas, gl_t* d_q, std::vector<gl_t>& apow, const gl_t* deltas8 = nullptr) {
     const gl_circuit_desc& d = cir->desc;
     const size_t n = cir->n, N = n << d.rate_bits;
     const uint32_t lgn = d.degree_bits, lgN = lgn + d.rate_bits;
@@ -407,12 +426,26 @@ static int quotient_chunks(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* w
     q.l0_coset = cir->d_l0_coset;
     q.n_field = (gl_t)n; q.lgN = lgN; q.num_constants = d.num_constants; q.num_selectors = d.num_selectors; q.num_gates = d.num_gates;
     q.next_step = 1u << d.rate_bits;
+    q.num_lookup_selectors = d.num_lookup_selectors; q.num_lookup_polys = d.num_lookup_polys;
+    q.gate_term0 = 2 + 2 * GLP_CHUNKS + (d.num_lookup_polys ? 2 * GLQ_LOOKUP_TERMS : 0);
+    if (d.num_lookup_polys) {
+        GL_REQUIRE(deltas8, GL_ERR_ARG, "a circuit with lookups needs the delta challenges");
+        for (int i = 0; i < 8; i++) q.deltas[i] = gl_canon(deltas8[i]);
+        for (int c = 0; c < 2; c++) {       // get_lut_poly(..).eval(delta) (vanishing_poly.rs:31-49): combos padded to whole table rows, reversed
+            const size_t deg = (d.lut_len + glhost::LOOKUP_TABLE_SLOTS - 1) / glhost::LOOKUP_TABLE_SLOTS * glhost::LOOKUP_TABLE_SLOTS;
+            gl_t f = 0;
+            for (size_t k = 0; k < deg; k++)
+                f = gl_add(gl_mul(f, q.deltas[4 * c + glhost::LU_CH_DELTA]), k < d.lut_len ? gl_add((gl_t)d.lut[2 * k], gl_mul(q.deltas[4 * c + glhost::LU_CH_B], (gl_t)d.lut[2 * k + 1])) : (gl_t)0);
+            q.lut_poly_at_delta[c] = gl_canon(f);
+        }
+    }
     for (unsigned g = 0; g < d.num_gates; g++) { q.gate_types[g] = d.gate_types[g]; q.gate_sel[g] = d.gate_selector_index[g]; q.group_start[g] = d.gate_group_start[g]; q.group_end[g] = d.gate_group_end[g]; }
     ctx->timing_begin("compute quotient polys");
     hipLaunchKernelGGL(k_quotient<false>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
     bool has_poseidon_gate = false;
     for (unsigned g = 0; g < d.num_gates; g++) has_poseidon_gate |= d.gate_types[g] == 4;
     if (has_poseidon_gate) hipLaunchKernelGGL(k_quotient<true>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
+    if (d.num_lookup_polys) hipLaunchKernelGGL(k_quotient_lookup, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
     ctx->timing_end();
     GL_CHECK_HIP(hipGetLastError());
     // coset_ifft(7) of each quotient (prover.rs:739-743); the 8n coefficients ARE the 8 chunks of n (prover.rs:245-258)
@@ -422,6 +455,7 @@ extern "C" int gl_quotient_polys(gl_ctx* ctx, const gl_circuit* cir, const gl_ba
                                  const uint64_t betas[2], const uint64_t gammas[2], const uint64_t alphas[2], gl_batch** out) {
     GL_TRY(check_phase_args(ctx, cir));
     GL_REQUIRE(pi_hash && betas && gammas && alphas && out, GL_ERR_ARG, "gl_quotient_polys: null argument");
+    GL_REQUIRE(!cir->desc.num_lookup_polys, GL_ERR_UNSUPPORTED, "the phase API does not carry the lookup challenges: prove circuits with lookups through gl_prove*");
     GL_TRY(check_batch(cir, wires, 135, "gl_quotient_polys: wires batch does not match the circuit"));
     GL_TRY(check_batch(cir, zs_partial_products, 20, "gl_quotient_polys: Z / partial-products batch does not match the circuit"));
     const size_t N = cir->n << cir->desc.rate_bits;
@@ -483,9 +517,10 @@ extern "C" int gl_fri_combine(gl_ctx* ctx, const gl_circuit* cir, const gl_batch
     GL_REQUIRE(batches && zeta_in && alpha_in && out, GL_ERR_ARG, "gl_fri_combine: null argument");
     const gl_circuit_desc& d = cir->desc;
     const size_t n = cir->n, N = n << d.rate_bits;
-    const size_t ncs = d.num_constants + 80, nopen = ncs + 135 + 20 + 16;
-    const size_t want[4] = {ncs, 135, 20, 16};
-    for (int o = 0; o < 4; o++) GL_TRY(check_batch(cir, batches[o], want[o], "gl_fri_combine: oracle order is constants||sigmas, wires, Z||partial products, quotient"));
+    const size_t nlk = 2 * (size_t)d.num_lookup_polys;                              // lookup polynomials: behind Z||partial products in oracle 2
+    const size_t ncs = d.num_constants + 80, nopen = ncs + 135 + 20 + 16 + nlk, nnext = 2 + nlk;
+    const size_t want[4] = {ncs, 135, 20 + nlk, 16};
+    for (int o = 0; o < 4; o++) GL_TRY(check_batch(cir, batches[o], want[o], "gl_fri_combine: oracle order is constants||sigmas, wires, Z||partial products(||lookups), quotient"));
     hipStream_t st = ctx->stream;
     std::unique_ptr<gl_fri, void (*)(gl_fri*)> f(new gl_fri(), gl_fri_free);
     f->ctx = ctx; ctx->retain(); f->desc = d; f->n = n; f->lgN = d.degree_bits + d.rate_bits;
@@ -499,19 +534,22 @@ extern "C" int gl_fri_combine(gl_ctx* ctx, const gl_circuit* cir, const gl_batch
         const uint32_t nseg = (uint32_t)((n + seg_len - 1) / seg_len);
         GL_TRY(d_F.alloc(2 * n * sizeof(gl_t)));
         GL_TRY(d_heads.alloc(2 * (size_t)nseg * sizeof(gl_t)));
-        GL_TRY(d_cols.alloc((nopen + 2) * sizeof(gl_t*)));
-        GL_TRY(d_apow.alloc(2 * (nopen + 2) * sizeof(gl_t)));
+        GL_TRY(d_cols.alloc((nopen + nnext) * sizeof(gl_t*)));
+        GL_TRY(d_apow.alloc(2 * (nopen + nnext) * sizeof(gl_t)));
         std::vector<const gl_t*>& cols = f->h_cols;
-        for (int o = 0; o < 4; o++) for (size_t c = 0; c < batches[o]->ncols; c++) cols.push_back(batches[o]->coeffs + c * n);
+        // fri_all_polys / fri_next_batch_polys (circuit_data.rs:564-597): the lookup polynomials come LAST in both batches
+        for (int o = 0; o < 4; o++) for (size_t c = 0; c < (o == 2 ? (size_t)20 : batches[o]->ncols); c++) cols.push_back(batches[o]->coeffs + c * n);
+        for (size_t c = 0; c < nlk; c++) cols.push_back(batches[2]->coeffs + (20 + c) * n);
         cols.push_back(batches[2]->coeffs); cols.push_back(batches[2]->coeffs + n);
-        std::vector<gl_t>& apow = f->h_apow; apow.assign(2 * (nopen + 2), 0);
+        for (size_t c = 0; c < nlk; c++) cols.push_back(batches[2]->coeffs + (20 + c) * n);
+        std::vector<gl_t>& apow = f->h_apow; apow.assign(2 * (nopen + nnext), 0);
         { gl2_t x = gl2_make(1, 0); for (size_t j = 0; j < nopen; j++) { apow[2 * j] = x.a; apow[2 * j + 1] = x.b; x = gl2_canon(gl2_mul(x, fri_alpha)); } }
-        { gl2_t x = gl2_make(1, 0); for (size_t j = 0; j < 2; j++) { apow[2 * (nopen + j)] = x.a; apow[2 * (nopen + j) + 1] = x.b; x = gl2_canon(gl2_mul(x, fri_alpha)); } }
+        gl2_t shift = gl2_make(1, 0);     // alpha^(#polys of batch 1) (reducing.rs:103-106)
+        { gl2_t x = gl2_make(1, 0); for (size_t j = 0; j < nnext; j++) { apow[2 * (nopen + j)] = x.a; apow[2 * (nopen + j) + 1] = x.b; x = gl2_canon(gl2_mul(x, fri_alpha)); } shift = x; }
         GL_TRY(h2d_async(ctx, d_cols.p, cols.data(), cols.size() * sizeof(gl_t*)));
         GL_TRY(h2d_async(ctx, d_apow.p, apow.data(), apow.size() * sizeof(gl_t)));
         gl_t* Fa = d_F.as<gl_t>(); gl_t* Fb = Fa + n;
         gl_t* Qa = f->coef->as<gl_t>(); gl_t* Qb = Qa + n;
-        const gl2_t shift = gl2_canon(gl2_mul(fri_alpha, fri_alpha));     // alpha^(#polys of batch 1) (reducing.rs:103-106)
         const unsigned gb = (unsigned)((n + 63) / 64), sb = (nseg + 63) / 64;      // k_fri_combine: 64 coefficients per workgroup
         ctx->timing_begin("reduce batch + divide by linear");
         // batch 0: all polynomials at zeta
@@ -520,7 +558,7 @@ extern "C" int gl_fri_combine(gl_ctx* ctx, const gl_circuit* cir, const gl_batch
         hipLaunchKernelGGL(k_div_linear_carries, dim3(1), dim3(1024), 0, st, d_heads.as<gl_t>(), (uint32_t)n, seg_len, zeta.a, zeta.b);
         hipLaunchKernelGGL(k_div_linear_apply, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, seg_len, zeta.a, zeta.b, d_heads.as<gl_t>(), shift.a, shift.b, Qa, Qb, 0);
         // batch 1: the Z polynomials at g * zeta
-        hipLaunchKernelGGL(k_fri_combine, dim3(gb), dim3(256), 0, st, d_cols.as<const gl_t*>() + nopen, d_apow.as<gl_t>() + 2 * nopen, 2u, (uint32_t)n, Fa, Fb);
+        hipLaunchKernelGGL(k_fri_combine, dim3(gb), dim3(256), 0, st, d_cols.as<const gl_t*>() + nopen, d_apow.as<gl_t>() + 2 * nopen, (uint32_t)nnext, (uint32_t)n, Fa, Fb);
         hipLaunchKernelGGL(k_div_linear_heads, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, seg_len, gzeta.a, gzeta.b, d_heads.as<gl_t>());
         hipLaunchKernelGGL(k_div_linear_carries, dim3(1), dim3(1024), 0, st, d_heads.as<gl_t>(), (uint32_t)n, seg_len, gzeta.a, gzeta.b);
         hipLaunchKernelGGL(k_div_linear_apply, dim3(sb), dim3(64), 0, st, Fa, Fb, (uint32_t)n, seg_len, gzeta.a, gzeta.b, d_heads.as<gl_t>(), (gl_t)1, (gl_t)0, Qa, Qb, 1);
@@ -798,14 +836,19 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     gl_t betas[2], gammas[2], alphas[2];
     for (int i = 0; i < 2; i++) betas[i] = ch.challenge();
     for (int i = 0; i < 2; i++) gammas[i] = ch.challenge();
+    // lookups: four coins per challenge, [betas | gammas | 4 more] (prover.rs:166-184)
+    const size_t nlk = 2 * (size_t)d.num_lookup_polys, nzs = 20 + nlk;
+    gl_t deltas[8] = {betas[0], betas[1], gammas[0], gammas[1], 0, 0, 0, 0};
+    if (nlk) for (int i = 4; i < 8; i++) deltas[i] = ch.challenge();
 
-    // ---- 6/7. partial products and Z, commitment (prover.rs:189-223) ----
+    // ---- 6/7. partial products and Z (and the lookup polynomials), commitment (prover.rs:189-223) ----
     BatchHolder zs;
     {
-        DevBuf d_zs(ctx); GL_TRY(d_zs.alloc(20 * n * sizeof(gl_t)));
+        DevBuf d_zs(ctx); GL_TRY(d_zs.alloc(nzs * n * sizeof(gl_t)));
         GL_TRY(partial_products_values(ctx, cir, d_wires, betas, gammas, d_zs.as<gl_t>()));
-        if (ctx->capture_intermediates) { proof->zs_pp.resize(20 * n); GL_TRY(d2h(ctx, proof->zs_pp.data(), d_zs.p, 20 * n * sizeof(gl_t))); }
-        GL_TRY(gl_batch_from_device(ctx, d_zs.as<uint64_t>(), 20, n, d.rate_bits, d.cap_height, 1, &zs.b));
+        if (nlk) GL_TRY(lookup_polys_values(ctx, cir, d_wires, deltas, d_zs.as<gl_t>() + 20 * n));
+        if (ctx->capture_intermediates) { proof->zs_pp.resize(nzs * n); GL_TRY(d2h(ctx, proof->zs_pp.data(), d_zs.p, nzs * n * sizeof(gl_t))); }
+        GL_TRY(gl_batch_from_device(ctx, d_zs.as<uint64_t>(), nzs, n, d.rate_bits, d.cap_height, 1, &zs.b));
     }
     d_wit.release();                                                            // stream-ordered: the kernels above are already queued
     GL_TRY(gl_batch_cap(zs.b, cap.data()));
@@ -817,7 +860,7 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     BatchHolder quot;
     {
         DevBuf d_q(ctx); GL_TRY(d_q.alloc(2 * N * sizeof(gl_t)));
-        GL_TRY(quotient_chunks(ctx, cir, wires.b, zs.b, pi_hash, betas, gammas, alphas, d_q.as<gl_t>(), h_apow_quot));
+        GL_TRY(quotient_chunks(ctx, cir, wires.b, zs.b, pi_hash, betas, gammas, alphas, d_q.as<gl_t>(), h_apow_quot, nlk ? deltas : nullptr));
         if (ctx->capture_intermediates) { proof->quotient.resize(16 * n); GL_TRY(d2h(ctx, proof->quotient.data(), d_q.p, 16 * n * sizeof(gl_t))); }
         GL_TRY(gl_batch_from_device(ctx, d_q.as<uint64_t>(), 16, n, d.rate_bits, d.cap_height, 0, &quot.b));
     }
@@ -837,8 +880,8 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
 
     // ---- 12. openings (proof.rs:306-344): all five evaluations behind one sync ----
     const gl_batch* oracles[4] = {cir->cs_batch, wires.b, zs.b, quot.b};
-    const size_t ncs = d.num_constants + 80, nopen = ncs + 135 + 20 + 16;
-    std::vector<gl_t> open_zeta(2 * nopen), open_next(2 * 2);
+    const size_t ncs = d.num_constants + 80, nopen = ncs + 135 + 20 + 16 + nlk, nnext = 2 + nlk;
+    std::vector<gl_t> open_zeta(2 * nopen), open_next(2 * nnext);
     {
         GL_TRY(ctx->ensure_dev_small(1 << 20));
         gl_t* d_open = ctx->dev_small + 4096;
@@ -848,18 +891,21 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
         gl_t* zp = d_zpow.as<gl_t>();
         hipLaunchKernelGGL(k_ext_powers2, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, st, zeta.a, zeta.b, gzeta.a, gzeta.b, (uint32_t)n, zp);
         // one launch for all 257 openings: the list of coefficient columns goes up as a small pointer table
-        for (int o = 0; o < 4; o++) for (size_t c = 0; c < oracles[o]->ncols; c++) h_open_cols.push_back(oracles[o]->coeffs + c * n);
+        // FriOpenings order (proof.rs:346-380): constants, sigmas, wires, zs, partial products, quotient, lookups | zs_next, lookups_next
+        for (int o = 0; o < 4; o++) for (size_t c = 0; c < (o == 2 ? (size_t)20 : oracles[o]->ncols); c++) h_open_cols.push_back(oracles[o]->coeffs + c * n);
+        for (size_t c = 0; c < nlk; c++) h_open_cols.push_back(zs.b->coeffs + (20 + c) * n);
         h_open_cols.push_back(zs.b->coeffs); h_open_cols.push_back(zs.b->coeffs + n);
+        for (size_t c = 0; c < nlk; c++) h_open_cols.push_back(zs.b->coeffs + (20 + c) * n);
         DevBuf d_open_cols(ctx); GL_TRY(d_open_cols.alloc(h_open_cols.size() * sizeof(gl_t*)));
         GL_TRY(h2d_async(ctx, d_open_cols.p, h_open_cols.data(), h_open_cols.size() * sizeof(gl_t*)));
         hipLaunchKernelGGL(k_eval_list_with_powers, dim3((unsigned)h_open_cols.size()), dim3(256), 0, st, d_open_cols.as<const gl_t*>(), (uint32_t)n,
                            (uint32_t)nopen, zp, zp + n, zp + 2 * n, zp + 3 * n, d_open);
         ctx->timing_end();
         GL_CHECK_HIP(hipGetLastError());
-        std::vector<gl_t> tmp(2 * nopen + 4);
+        std::vector<gl_t> tmp(2 * (nopen + nnext));
         GL_TRY(d2h(ctx, tmp.data(), d_open, tmp.size() * sizeof(gl_t)));
         memcpy(open_zeta.data(), tmp.data(), 2 * nopen * sizeof(gl_t));
-        memcpy(open_next.data(), tmp.data() + 2 * nopen, 4 * sizeof(gl_t));
+        memcpy(open_next.data(), tmp.data() + 2 * nopen, 2 * nnext * sizeof(gl_t));
     }
     // FriOpenings order = oracle order: constants, sigmas, wires, zs, partial products, quotient; then zs_next
     ch.observe_many(open_zeta.data(), open_zeta.size());
@@ -901,14 +947,16 @@ static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wire
     std::vector<uint8_t>& o = proof->bytes;
     o.reserve(query_blob.size() + 8 * (npis + 2 * nopen + fin_words + 4 * ncap) + 4096);
     put_words(o, proof->caps.data(), proof->caps.size());                        // wires_cap, zs_pp_cap, quotient_cap
-    // OpeningSet (:1409-1423): constants, sigmas, wires, zs, zs_next, [lookups: empty], partial products, quotient
+    // OpeningSet (:1409-1423): constants, sigmas, wires, zs, zs_next, lookup_zs, lookup_zs_next, partial products, quotient
     {
         const gl_t* z = open_zeta.data();
-        size_t o_cs = 0, o_w = 2 * ncs, o_z = o_w + 2 * 135, o_pp = o_z + 2 * 2, o_q = o_z + 2 * 20;
+        size_t o_cs = 0, o_w = 2 * ncs, o_z = o_w + 2 * 135, o_pp = o_z + 2 * 2, o_q = o_z + 2 * 20, o_lk = o_q + 2 * 16;
         put_words(o, z + o_cs, 2 * ncs);
         put_words(o, z + o_w, 2 * 135);
         put_words(o, z + o_z, 2 * 2);
         put_words(o, open_next.data(), 2 * 2);
+        put_words(o, z + o_lk, 2 * nlk);
+        put_words(o, open_next.data() + 2 * 2, 2 * nlk);
         put_words(o, z + o_pp, 2 * 18);
         put_words(o, z + o_q, 2 * 16);
     }

@@ -155,9 +155,9 @@ __global__ __launch_bounds__(256) void k_z_finalize(const gl_t* row_prod, const 
 struct GlQuotParams {
     const gl_t* cs;             // constants||sigmas LDE [num_constants + 80][N] natural order
     const gl_t* wires;          // wires LDE [135][N]
-    const gl_t* zs;             // Z||partial products LDE [20][N]
+    const gl_t* zs;             // Z||partial products(||lookup polynomials) LDE [20 (+ 14)][N]
     const gl_t* xpow_lo; const gl_t* xpow_hi;    // 7 * w_N^i two-level
-    const gl_t* alpha_pows;     // [2][152]: alpha_b^t
+    const gl_t* alpha_pows;     // [2][GLQ_MAX_TERMS]: alpha_b^t
     gl_t* out;                  // [2][N]
     gl_t k_is[GLP_MAX_ROUTED];
     gl_t betas[2], gammas[2];
@@ -169,8 +169,14 @@ struct GlQuotParams {
     uint32_t k_is_powers_of_7;
     uint8_t gate_types[8];
     uint32_t gate_sel[8], group_start[8], group_end[8];
+    // lookup argument (zero without lookups): the lookup selector columns sit between the gate selectors and the gates' constants, the
+    // lookup polynomials behind Z and the partial products, their 2 x 17 terms between the partial-product checks and the gate terms
+    uint32_t num_lookup_selectors, num_lookup_polys, gate_term0;
+    gl_t deltas[8];                 // per challenge: ChallengeA, ChallengeB, ChallengeAlpha, ChallengeDelta (circuit_builder.rs:61-71)
+    gl_t lut_poly_at_delta[2];      // get_lut_poly(..).eval(delta) per challenge (vanishing_poly.rs:31-49), computed on the host
 };
-#define GLQ_MAX_TERMS 152
+#define GLQ_MAX_TERMS 192
+#define GLQ_LOOKUP_TERMS 17         // per challenge: last LDC, initial Sum, initial RE, final RE (one table), RE transition, 6 x (Sum, LDC) transitions
 
 // running alpha-weighted sums for the two alphas: unreduced (GlxWideAcc2: 16 instructions per term for both), one reduction
 // when the sum is used
@@ -327,8 +333,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     tot0 = terms.sum(0); tot1 = terms.sum(1);
     }
     // gate constraints: sum_g filter_g * sum_j alpha^(22+j) c_{g,j}   (vanishing_poly.rs:706-732, gate.rs:121-146)
-    const uint32_t T0 = 2 + 2 * GLP_CHUNKS;
-    const gl_t* gc = cs + (size_t)p.num_selectors * N;              // the gate's own constants
+    const uint32_t T0 = p.gate_term0;                               // 2 + 2 * GLP_CHUNKS, + 2 x 17 lookup terms when there are lookups
+    const gl_t* gc = cs + (size_t)(p.num_selectors + p.num_lookup_selectors) * N;      // the gate's own constants (gate.rs:129-133)
 #pragma unroll 1
     for (uint32_t g = 0; g < p.num_gates; g++) {
         if ((p.gate_types[g] == 4) != POSEIDON_PART) continue;
@@ -391,6 +397,118 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     } else {
         p.out[i] = o0;
         p.out[N + i] = o1;
+    }
+}
+
+// ---- lookup argument: check_lookup_constraints_batch (plonk/vanishing_poly.rs:503-670) on the LDE points -----------------------------
+// One thread per point, both challenges; ADDS sum_t alpha^t term_t / Z_H(x) to what k_quotient wrote (the combination is linear).
+// Only circuits with a lookup table launch it; every operand is canonical.
+__global__ __launch_bounds__(256) void k_quotient_lookup(GlQuotParams p) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t N = size_t(1) << p.lgN;
+    if (i >= N) return;
+    const gl_t* w = p.wires + i;
+    const gl_t* sel = p.cs + i + (size_t)p.num_selectors * N;       // lookup selectors: TransSre, TransLdc, InitSre, LastLdc, end of the table
+    const uint32_t i_next = (i + p.next_step) & (uint32_t)(N - 1);
+    const uint32_t NLP = p.num_lookup_polys, num_sldc = NLP - 1;    // 7 and 6
+    const gl_t s_trans_sre = sel[0], s_trans_ldc = sel[N], s_init = sel[2 * N], s_last = sel[3 * N], s_end = sel[4 * N];
+    gl_t tot[2];
+    for (int c = 0; c < 2; c++) {
+        const gl_t* ap = p.alpha_pows + (size_t)c * GLQ_MAX_TERMS;
+        const gl_t ca = p.deltas[4 * c], cb = p.deltas[4 * c + 1], calpha = p.deltas[4 * c + 2], cdelta = p.deltas[4 * c + 3];
+        gl_t acc = 0;
+        for (int ch = 0; ch < 2; ch++) {
+            // terms of challenge `ch` weighted by THIS output's alpha: t = 22 + 17 ch + k
+            const gl_t da = p.deltas[4 * ch], db = p.deltas[4 * ch + 1], dalpha = p.deltas[4 * ch + 2], ddelta = p.deltas[4 * ch + 3];
+            const gl_t* lz = p.zs + i + (size_t)(2 * GLP_CHUNKS + ch * NLP) * N;
+            const gl_t* lzn = p.zs + i_next + (size_t)(2 * GLP_CHUNKS + ch * NLP) * N;
+            const gl_t z_re = lz[0], next_z_re = lzn[0];
+            uint32_t t = 2 + 2 * GLP_CHUNKS + GLQ_LOOKUP_TERMS * ch;
+            auto term = [&](gl_t v) { acc = gl_add(acc, gl_mul(v, ap[t])); t++; };
+            term(gl_mul(s_last, lz[(size_t)num_sldc * N]));                       // last LDC: z_x_sldc[num_sldc - 1]
+            term(gl_mul(s_init, lz[N]));                                          // initial Sum: z_x_sldc[0]
+            term(gl_mul(s_init, z_re));                                           // initial RE
+            term(gl_mul(s_end, gl_sub(z_re, p.lut_poly_at_delta[ch])));           // final RE
+            gl_t cur = next_z_re;                                                 // RE transition
+#pragma unroll 1
+            for (int sl = 0; sl < 26; sl++) cur = gl_add(gl_mul(cur, ddelta), gl_add(w[(size_t)(3 * sl) * N], gl_mul(db, w[(size_t)(3 * sl + 1) * N])));
+            term(gl_mul(s_trans_sre, gl_sub(z_re, cur)));
+#pragma unroll 1
+            for (uint32_t poly = 0; poly < num_sldc; poly++) {
+                // alpha - (inp + a out) of the table slots [5 poly, min(5 poly + 5, 26)) and of the lookup slots [7 poly, min(7 poly + 7, 40))
+                const uint32_t t0 = poly * 5, t1 = (t0 + 5 < 26) ? t0 + 5 : 26, u0 = poly * 7, u1 = (u0 + 7 < 40) ? u0 + 7 : 40;
+                gl_t ft[5], fu[7];
+                for (uint32_t a = t0; a < t1; a++) ft[a - t0] = gl_sub(dalpha, gl_add(w[(size_t)(3 * a) * N], gl_mul(da, w[(size_t)(3 * a + 1) * N])));
+                for (uint32_t a = u0; a < u1; a++) fu[a - u0] = gl_sub(dalpha, gl_add(w[(size_t)(2 * a) * N], gl_mul(da, w[(size_t)(2 * a + 1) * N])));
+                gl_t lut_prod = 1, lu_prod = 1, lu_sum = 0, lut_sum_mul = 0;
+                for (uint32_t a = 0; a < t1 - t0; a++) lut_prod = gl_mul(lut_prod, ft[a]);
+                for (uint32_t a = 0; a < u1 - u0; a++) lu_prod = gl_mul(lu_prod, fu[a]);
+                for (uint32_t a = 0; a < u1 - u0; a++) { gl_t pr = 1; for (uint32_t b = 0; b < u1 - u0; b++) if (b != a) pr = gl_mul(pr, fu[b]); lu_sum = gl_add(lu_sum, pr); }
+                for (uint32_t a = 0; a < t1 - t0; a++) { gl_t pr = 1; for (uint32_t b = 0; b < t1 - t0; b++) if (b != a) pr = gl_mul(pr, ft[b]); lut_sum_mul = gl_add(lut_sum_mul, gl_mul(w[(size_t)(3 * (t0 + a) + 2) * N], pr)); }
+                const gl_t prev = poly == 0 ? lzn[(size_t)num_sldc * N] : lz[(size_t)poly * N];
+                const gl_t dz = gl_sub(lz[(size_t)(poly + 1) * N], prev);
+                term(gl_mul(s_trans_sre, gl_sub(gl_mul(lut_prod, dz), lut_sum_mul)));
+                term(gl_mul(s_trans_ldc, gl_add(gl_mul(lu_prod, dz), lu_sum)));
+            }
+            (void)ca; (void)cb; (void)calpha; (void)cdelta;
+        }
+        tot[c] = acc;
+    }
+    const gl_t zi = p.zh_inv[i & 7];
+    p.out[i] = gl_canon(gl_add(p.out[i], gl_mul(tot[0], zi)));
+    p.out[N + i] = gl_canon(gl_add(p.out[N + i], gl_mul(tot[1], zi)));
+}
+
+// compute_lookup_polys (plonk/prover.rs:425-541).  Step 1: 1 / (alpha - (inp + a out)) for every slot of every lookup row, in parallel:
+// grid = (rows from last_lu_row to first_lut_row, 2 challenges), block = 64 (slot = thread).  inv[ch][row - last_lu_row][64]
+__global__ __launch_bounds__(64) void k_lookup_inverses(const gl_t* __restrict__ wires, uint32_t n, uint32_t last_lu_row, uint32_t last_lut_row,
+                                                        gl_t a0, gl_t alpha0, gl_t a1, gl_t alpha1, gl_t* __restrict__ inv) {
+    const uint32_t row = last_lu_row + blockIdx.x, ch = blockIdx.y, sl = threadIdx.x;
+    const bool table_row = row >= last_lut_row;
+    const uint32_t nslots = table_row ? 26u : 40u, stride = table_row ? 3u : 2u;
+    gl_t v = 0;
+    if (sl < nslots) {
+        const gl_t inp = wires[(size_t)(stride * sl) * n + row], outv = wires[(size_t)(stride * sl + 1) * n + row];
+        const gl_t a = ch ? a1 : a0, alpha = ch ? alpha1 : alpha0;
+        v = gl_canon(gl_inv(gl_sub(alpha, gl_add(inp, gl_mul(a, outv)))));
+    }
+    inv[((size_t)ch * gridDim.x + blockIdx.x) * 64 + sl] = v;
+}
+// Step 2: the running sums, sequential over the (few) rows: thread c = challenge c.  Writes the 7 columns of its challenge (RE, 6 partial
+// SLDC), which the caller zeroed: out[(7 c + k) * n + row].
+__global__ void k_lookup_scan(const gl_t* __restrict__ wires, uint32_t n, uint32_t last_lu_row, uint32_t last_lut_row, uint32_t first_lut_row,
+                              gl_t b0, gl_t delta0, gl_t b1, gl_t delta1, const gl_t* __restrict__ inv, gl_t* __restrict__ out) {
+    const uint32_t c = threadIdx.x;
+    if (c >= 2) return;
+    const gl_t cb = c ? b1 : b0, cdelta = c ? delta1 : delta0;
+    const uint32_t nrows = first_lut_row - last_lu_row + 1;
+    const gl_t* iv = inv + (size_t)c * nrows * 64;
+    gl_t* o = out + (size_t)(7 * c) * n;
+    gl_t re_next = 0, last_next = 0;                           // RE and the last partial polynomial on the row above (0 above the first table row)
+    for (uint32_t row = first_lut_row + 1; row-- > last_lut_row;) {          // partial Sums and RE, from the first table row down
+        const gl_t* r = iv + (size_t)(row - last_lu_row) * 64;
+        gl_t re = re_next;
+        for (uint32_t sl = 0; sl < 26; sl++) re = gl_add(gl_mul(re, cdelta), gl_add(wires[(size_t)(3 * sl) * n + row], gl_mul(cb, wires[(size_t)(3 * sl + 1) * n + row])));
+        o[row] = gl_canon(re); re_next = re;
+        gl_t sum = last_next;
+        for (uint32_t slot = 0; slot < 6; slot++) {
+            const uint32_t s0 = slot * 5, s1 = (s0 + 5 < 26) ? s0 + 5 : 26;
+            for (uint32_t sl = s0; sl < s1; sl++) sum = gl_add(sum, gl_mul(wires[(size_t)(3 * sl + 2) * n + row], r[sl]));
+            o[(size_t)(slot + 1) * n + row] = gl_canon(sum);
+        }
+        last_next = sum;
+    }
+    for (uint32_t row = last_lut_row; row-- > last_lu_row;) {                // partial LDCs
+        const gl_t* r = iv + (size_t)(row - last_lu_row) * 64;
+        gl_t cur = last_next;
+        for (uint32_t slot = 0; slot < 6; slot++) {
+            const uint32_t s0 = slot * 7, s1 = (s0 + 7 < 40) ? s0 + 7 : 40;
+            gl_t sum = 0;
+            for (uint32_t sl = s0; sl < s1; sl++) sum = gl_add(sum, r[sl]);
+            cur = gl_sub(cur, sum);
+            o[(size_t)(slot + 1) * n + row] = gl_canon(cur);
+        }
+        last_next = cur;
     }
 }
 

@@ -414,8 +414,8 @@ class OracleProof:
         self.c.o.lib.orc_proof_caps(self.h, _p(out))
         return out
 
-    def zs_partial_products(self):
-        out = np.empty((20, self.c.n), dtype=np.uint64)
+    def zs_partial_products(self, ncols=20):
+        out = np.empty((ncols, self.c.n), dtype=np.uint64)
         self.c.o.lib.orc_proof_zs_partial_products(self.h, _p(out))
         return out
 
