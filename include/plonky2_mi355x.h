@@ -64,7 +64,7 @@ typedef struct gl_proof gl_proof;      /* ProofWithPublicInputs + the prover's i
  * 380-440) besides the constants/sigma value columns.  Gate types: 0 Noop, 1 Constant, 2 PublicInput,
  * 3 Arithmetic(20 ops), 4 Poseidon -- the gate set of the matmul demo circuit -- and 5 BaseSumGate<2> with the 63 limbs
  * of BaseSumGate::new_from_config (gates/base_sum.rs:31-35; range_check / split_le), 6 LookupGate and 7 LookupTableGate
- * (the lookup argument: fields at the end of this struct; gl_prove* only, the phase API returns GL_ERR_UNSUPPORTED); `gate_types` is the list
+ * (the lookup argument: fields at the end of this struct; phase API: the *_lookups variants); `gate_types` is the list
  * `common_data.gates` (sorted by degree, id) and the group arrays are `selectors_info`
  * (plonky2/src/gates/selectors.rs:17-26). */
 typedef struct gl_circuit_desc {
@@ -249,6 +249,16 @@ int gl_partial_products(gl_ctx* ctx, const gl_circuit* c, const uint64_t* d_wire
 int gl_quotient_polys(gl_ctx* ctx, const gl_circuit* c, const gl_batch* wires, const gl_batch* zs_partial_products,
                       const uint64_t public_inputs_hash[4], const uint64_t betas[2], const uint64_t gammas[2],
                       const uint64_t alphas[2], gl_batch** out);
+/* The same two phases for a circuit WITH the lookup argument: `deltas[8]` = per challenge ChallengeA, ChallengeB, ChallengeAlpha,
+ * ChallengeDelta, i.e. [betas | gammas | the 4 challenges drawn after them] (plonk/prover.rs:166-184).  The batch of the first has the
+ * 2 x 7 lookup polynomials behind the 20 columns (compute_all_lookup_polys, prover.rs:202-211); the second adds
+ * check_lookup_constraints (vanishing_poly.rs:503-670) to the quotient.  gl_fri_combine and gl_open_at need no variant: the batch
+ * carries its columns (openings in FriOpenings order: ..., quotient, lookups | zs_next, lookups_next, plonk/proof.rs:346-380). */
+int gl_partial_products_lookups(gl_ctx* ctx, const gl_circuit* c, const uint64_t* d_wires, const uint64_t betas[2],
+                                const uint64_t gammas[2], const uint64_t deltas[8], gl_batch** out);
+int gl_quotient_polys_lookups(gl_ctx* ctx, const gl_circuit* c, const gl_batch* wires, const gl_batch* zs_partial_products_lookups,
+                              const uint64_t public_inputs_hash[4], const uint64_t betas[2], const uint64_t gammas[2],
+                              const uint64_t alphas[2], const uint64_t deltas[8], gl_batch** out);
 /* OpeningSet::new's eval_commitment (plonk/proof.rs:306-344): polynomials first_col .. first_col + num_cols of a
  * batch at the extension point z; h_out[num_cols][2]. */
 int gl_open_at(gl_ctx* ctx, const gl_batch* b, const uint64_t z[2], size_t first_col, size_t num_cols, uint64_t* h_out);

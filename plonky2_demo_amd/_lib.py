@@ -98,6 +98,8 @@ SIGNATURES = {
     "gl_circuit_free": (None, [c_vp]),
     "gl_partial_products": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "gl_quotient_polys": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_vp)]),
+    "gl_partial_products_lookups": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_vp)]),
+    "gl_quotient_polys_lookups": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "gl_open_at": (c_int, [c_vp, c_vp, c_vp, c_sz, c_sz, c_vp]),
     "gl_fri_combine": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "gl_fri_commit_round": (c_int, [c_vp, c_vp]),

@@ -491,12 +491,53 @@ def _prove_columns(ctx, circuit_handle, n, columns, public_inputs):
     return Proof(h.value, n)
 
 
-class CircuitData:
+class _PhaseApi:
+    """The phase-level seam of a device-resident circuit, for a caller that owns the Challenger; `self.desc` is the
+    gl_circuit_desc, `self.handle` the gl_circuit.  Circuits with the lookup argument pass the 8 delta challenges."""
+
+    def _batch(self, handle, ctx):
+        return PolynomialBatch(handle, ctx, self.desc.rate_bits, self.desc.cap_height)
+
+    @property
+    def constants_sigmas_batch(self):
+        """`prover_data.constants_sigmas_commitment` (borrowed: owned by the circuit)."""
+        b = self._batch(lib.gl_circuit_constants_sigmas_batch(self.handle), self.ctx)
+        b.handle_owned = False
+        return b
+
+    def partial_products(self, d_wires_ptr, betas, gammas, ctx=None, deltas=None):
+        """all_wires_permutation_partial_products (+ compute_all_lookup_polys) + commitment (plonk/prover.rs:189-223)."""
+        ctx = ctx or self.ctx
+        h = ctypes.c_void_p()
+        if deltas is None:
+            check(lib.gl_partial_products(ctx.handle, self.handle, d_wires_ptr, _p(_u64(betas)), _p(_u64(gammas)), ctypes.byref(h)))
+        else:
+            check(lib.gl_partial_products_lookups(ctx.handle, self.handle, d_wires_ptr, _p(_u64(betas)), _p(_u64(gammas)), _p(_u64(deltas)), ctypes.byref(h)))
+        return self._batch(h.value, ctx)
+
+    def quotient_polys(self, wires_batch, zs_batch, public_inputs_hash, betas, gammas, alphas, ctx=None, deltas=None):
+        """compute_quotient_polys + chunking + commitment (plonk/prover.rs:229-271)."""
+        ctx = ctx or self.ctx
+        h = ctypes.c_void_p()
+        if deltas is None:
+            check(lib.gl_quotient_polys(ctx.handle, self.handle, wires_batch.handle, zs_batch.handle, _p(_u64(public_inputs_hash)),
+                                        _p(_u64(betas)), _p(_u64(gammas)), _p(_u64(alphas)), ctypes.byref(h)))
+        else:
+            check(lib.gl_quotient_polys_lookups(ctx.handle, self.handle, wires_batch.handle, zs_batch.handle, _p(_u64(public_inputs_hash)),
+                                                _p(_u64(betas)), _p(_u64(gammas)), _p(_u64(alphas)), _p(_u64(deltas)), ctypes.byref(h)))
+        return self._batch(h.value, ctx)
+
+    def fri(self, batches, zeta, alpha, ctx=None):
+        """PolynomialBatch::prove_openings up to fri_proof (fri/oracle.rs:162-204)."""
+        return FriProver(self, batches, zeta, alpha, ctx or self.ctx)
+
+
+class CircuitData(_PhaseApi):
     """plonky2::plonk::circuit_data::CircuitData for the prover: `prove(wires, public_inputs)` mirrors
     CircuitData::prove (circuit_data.rs:144-151) at the full-witness boundary."""
 
     def __init__(self, host, ctx):
-        self.host, self.ctx = host, ctx
+        self.host, self.ctx, self.desc = host, ctx, host.desc
         h = ctypes.c_void_p()
         check(lib.gl_circuit_from_host(ctx.handle, host.handle, ctypes.byref(h)))
         self.handle = h.value
@@ -512,36 +553,6 @@ class CircuitData:
         out = np.empty((1 << self.host.desc.cap_height, 4), dtype=np.uint64)
         check(lib.gl_circuit_constants_sigmas_cap(self.handle, _p(out)))
         return out
-
-    # ---- prover phases (the seam for a caller that owns the Challenger) ----
-    def _batch(self, handle, ctx):
-        return PolynomialBatch(handle, ctx, self.host.desc.rate_bits, self.host.desc.cap_height)
-
-    @property
-    def constants_sigmas_batch(self):
-        """`prover_data.constants_sigmas_commitment` (borrowed: owned by the circuit)."""
-        b = self._batch(lib.gl_circuit_constants_sigmas_batch(self.handle), self.ctx)
-        b.handle_owned = False
-        return b
-
-    def partial_products(self, d_wires_ptr, betas, gammas, ctx=None):
-        """all_wires_permutation_partial_products + commitment (plonk/prover.rs:189-223)."""
-        ctx = ctx or self.ctx
-        h = ctypes.c_void_p()
-        check(lib.gl_partial_products(ctx.handle, self.handle, d_wires_ptr, _p(_u64(betas)), _p(_u64(gammas)), ctypes.byref(h)))
-        return self._batch(h.value, ctx)
-
-    def quotient_polys(self, wires_batch, zs_batch, public_inputs_hash, betas, gammas, alphas, ctx=None):
-        """compute_quotient_polys + chunking + commitment (plonk/prover.rs:229-271)."""
-        ctx = ctx or self.ctx
-        h = ctypes.c_void_p()
-        check(lib.gl_quotient_polys(ctx.handle, self.handle, wires_batch.handle, zs_batch.handle, _p(_u64(public_inputs_hash)),
-                                    _p(_u64(betas)), _p(_u64(gammas)), _p(_u64(alphas)), ctypes.byref(h)))
-        return self._batch(h.value, ctx)
-
-    def fri(self, batches, zeta, alpha, ctx=None):
-        """PolynomialBatch::prove_openings up to fri_proof (fri/oracle.rs:162-204)."""
-        return FriProver(self, batches, zeta, alpha, ctx or self.ctx)
 
     def verify(self, proof):
         """CircuitData::verify (plonk/circuit_data.rs:153-155); `proof` is a Proof or its bytes."""
@@ -574,7 +585,7 @@ class CircuitData:
             pass
 
 
-class GenericCircuitData:
+class GenericCircuitData(_PhaseApi):
     """Prover + verifier for ANY circuit over the demo's gate set, given what CircuitBuilder::build() produces: the descriptor
     (CommonCircuitData) and the constants || sigmas value columns (gl_circuit_create)."""
 
@@ -759,7 +770,7 @@ class FriProver:
         self.handle = h.value
 
     def commit_round(self):
-        cap = np.empty((1 << self.cd.host.desc.cap_height, 4), dtype=np.uint64)
+        cap = np.empty((1 << self.cd.desc.cap_height, 4), dtype=np.uint64)
         check(lib.gl_fri_commit_round(self.handle, _p(cap)))
         return cap
 

@@ -387,13 +387,23 @@ static int check_batch(const gl_circuit* cir, const gl_batch* b, size_t ncols, c
     GL_REQUIRE(b && b->ncols == ncols && b->n == cir->n && b->rate_bits == cir->desc.rate_bits && b->cap_height == cir->desc.cap_height, GL_ERR_ARG, what);
     return GL_OK;
 }
-extern "C" int gl_partial_products(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t betas[2], const uint64_t gammas[2], gl_batch** out) {
+static int partial_products_phase(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t* betas, const uint64_t* gammas, const uint64_t* deltas8, gl_batch** out) {
     GL_TRY(check_phase_args(ctx, cir));
     GL_REQUIRE(d_wires && betas && gammas && out, GL_ERR_ARG, "gl_partial_products: null argument");
-    GL_REQUIRE(!cir->desc.num_lookup_polys, GL_ERR_UNSUPPORTED, "the phase API does not carry the lookup challenges: prove circuits with lookups through gl_prove*");
-    DevBuf d_zs(ctx); GL_TRY(d_zs.alloc(20 * cir->n * sizeof(gl_t)));
+    const size_t nlk = 2 * (size_t)cir->desc.num_lookup_polys, nzs = 20 + nlk;
+    GL_REQUIRE((nlk != 0) == (deltas8 != nullptr), GL_ERR_ARG, "circuits with lookups take gl_partial_products_lookups (with the delta challenges), circuits without take gl_partial_products");
+    DevBuf d_zs(ctx); GL_TRY(d_zs.alloc(nzs * cir->n * sizeof(gl_t)));
     GL_TRY(partial_products_values(ctx, cir, d_wires, betas, gammas, d_zs.as<gl_t>()));
-    return gl_batch_from_device(ctx, d_zs.as<uint64_t>(), 20, cir->n, cir->desc.rate_bits, cir->desc.cap_height, 1, out);
+    if (nlk) GL_TRY(lookup_polys_values(ctx, cir, d_wires, deltas8, d_zs.as<gl_t>() + 20 * cir->n));
+    return gl_batch_from_device(ctx, d_zs.as<uint64_t>(), nzs, cir->n, cir->desc.rate_bits, cir->desc.cap_height, 1, out);
+}
+extern "C" int gl_partial_products(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t betas[2], const uint64_t gammas[2], gl_batch** out) {
+    return partial_products_phase(ctx, cir, d_wires, betas, gammas, nullptr, out);
+}
+extern "C" int gl_partial_products_lookups(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* d_wires, const uint64_t betas[2], const uint64_t gammas[2],
+                                           const uint64_t deltas[8], gl_batch** out) {
+    GL_REQUIRE(deltas, GL_ERR_ARG, "gl_partial_products_lookups: null deltas");
+    return partial_products_phase(ctx, cir, d_wires, betas, gammas, deltas, out);
 }
 
 // ---- 9. compute_quotient_polys + split (plonk/prover.rs:229-258,574-744): d_q[2][8n] -> the 16 chunk COEFFICIENT columns ----
@@ -451,17 +461,29 @@ static int quotient_chunks(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* w
     // coset_ifft(7) of each quotient (prover.rs:739-743); the 8n coefficients ARE the 8 chunks of n (prover.rs:245-258)
     return gl_ntt_run(ctx, d_q, N, (uint32_t)N, d_q, N, lgN, 2, true, 0, gl_canon(gl_inv(GL_MULT_GENERATOR)), gl_host_inverse_2exp(lgN));
 }
+static int quotient_phase(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* wires, const gl_batch* zs_partial_products, const uint64_t* pi_hash,
+                          const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas, const uint64_t* deltas8, gl_batch** out);
 extern "C" int gl_quotient_polys(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* wires, const gl_batch* zs_partial_products, const uint64_t pi_hash[4],
                                  const uint64_t betas[2], const uint64_t gammas[2], const uint64_t alphas[2], gl_batch** out) {
+    return quotient_phase(ctx, cir, wires, zs_partial_products, pi_hash, betas, gammas, alphas, nullptr, out);
+}
+extern "C" int gl_quotient_polys_lookups(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* wires, const gl_batch* zs_partial_products_lookups, const uint64_t pi_hash[4],
+                                         const uint64_t betas[2], const uint64_t gammas[2], const uint64_t alphas[2], const uint64_t deltas[8], gl_batch** out) {
+    GL_REQUIRE(deltas, GL_ERR_ARG, "gl_quotient_polys_lookups: null deltas");
+    return quotient_phase(ctx, cir, wires, zs_partial_products_lookups, pi_hash, betas, gammas, alphas, deltas, out);
+}
+static int quotient_phase(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* wires, const gl_batch* zs_partial_products, const uint64_t* pi_hash,
+                          const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas, const uint64_t* deltas8, gl_batch** out) {
     GL_TRY(check_phase_args(ctx, cir));
     GL_REQUIRE(pi_hash && betas && gammas && alphas && out, GL_ERR_ARG, "gl_quotient_polys: null argument");
-    GL_REQUIRE(!cir->desc.num_lookup_polys, GL_ERR_UNSUPPORTED, "the phase API does not carry the lookup challenges: prove circuits with lookups through gl_prove*");
+    const size_t nlk = 2 * (size_t)cir->desc.num_lookup_polys;
+    GL_REQUIRE((nlk != 0) == (deltas8 != nullptr), GL_ERR_ARG, "circuits with lookups take gl_quotient_polys_lookups (with the delta challenges), circuits without take gl_quotient_polys");
     GL_TRY(check_batch(cir, wires, 135, "gl_quotient_polys: wires batch does not match the circuit"));
-    GL_TRY(check_batch(cir, zs_partial_products, 20, "gl_quotient_polys: Z / partial-products batch does not match the circuit"));
+    GL_TRY(check_batch(cir, zs_partial_products, 20 + nlk, "gl_quotient_polys: Z / partial-products (/ lookups) batch does not match the circuit"));
     const size_t N = cir->n << cir->desc.rate_bits;
     DevBuf d_q(ctx); GL_TRY(d_q.alloc(2 * N * sizeof(gl_t)));
     std::vector<gl_t> apow;
-    GL_TRY(quotient_chunks(ctx, cir, wires, zs_partial_products, pi_hash, betas, gammas, alphas, d_q.as<gl_t>(), apow));
+    GL_TRY(quotient_chunks(ctx, cir, wires, zs_partial_products, pi_hash, betas, gammas, alphas, d_q.as<gl_t>(), apow, deltas8));
     int rc = gl_batch_from_device(ctx, d_q.as<uint64_t>(), 16, cir->n, cir->desc.rate_bits, cir->desc.cap_height, 0, out);
     GL_CHECK_HIP(gl_stream_wait(ctx->stream));      // `apow` was the source of an async upload
     return rc;

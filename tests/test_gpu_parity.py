@@ -905,6 +905,70 @@ def test_lookup_argument_circuits(gpu, orc, kind, param, inputs):
     assert zs_g[20:].any()
 
 
+def test_phase_api_on_a_lookup_circuit_with_an_external_transcript(gpu, orc):
+    # the phase-level seam for a circuit WITH lookups: gl_partial_products_lookups / gl_quotient_polys_lookups take the delta challenges
+    # ([betas | gammas | 4 drawn after them], prover.rs:166-184); openings in FriOpenings order with the lookup polynomials last in both
+    # batches (proof.rs:346-380); OpeningSet bytes with the lookup vectors between zs_next and the partial products (mod.rs:1409-1423).
+    # The bytes assembled by the caller equal gl_prove's and the oracle's.
+    p, ctx = gpu
+    oc = orc.circuit_of_kind(8, 50, threads=8)
+    w = oc.witness(np.arange(3, 53, dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=9)
+    wires, pis = w.wires(), w.public_inputs()
+    op = w.prove(threads=8)
+    d = oc.product_desc()
+    cd = p.GenericCircuitData(d, oc.constants_sigmas())
+    n, N = 1 << d.degree_bits, 1 << (d.degree_bits + 3)
+    d_w = ctx.alloc(wires.nbytes).upload(wires)
+    ch = _Challenger(orc)
+    pi_hash = orc.hash_no_pad(pis)
+    ch.observe(cd.circuit_digest); ch.observe(pi_hash)
+    wires_b = p.PolynomialBatch.from_device(d_w.ptr, 135, n, d.rate_bits, d.cap_height, True)
+    ch.observe(wires_b.cap)
+    betas, gammas = ch.get(2), ch.get(2)
+    deltas = list(betas) + list(gammas) + list(ch.get(4))
+    with pytest.raises(p.Plonky2Mi355xError):
+        cd.partial_products(d_w.ptr, betas, gammas)                        # a lookup circuit needs the deltas
+    zs_b = cd.partial_products(d_w.ptr, betas, gammas, deltas=deltas)
+    assert zs_b.polynomials.shape[0] == 34
+    ch.observe(zs_b.cap)
+    alphas = ch.get(2)
+    q_b = cd.quotient_polys(wires_b, zs_b, pi_hash, betas, gammas, alphas, deltas=deltas)
+    assert (q_b.polynomials == op.quotient_chunks()).all()
+    ch.observe(q_b.cap)
+    zeta = ch.get(2)
+    g = orc.primitive_root(d.degree_bits)
+    gzeta = [zeta[0] * g % P, zeta[1] * g % P]
+    cs_b = cd.constants_sigmas_batch
+    o_cs, o_w, o_z, o_q = cs_b.open_at(zeta), wires_b.open_at(zeta), zs_b.open_at(zeta), q_b.open_at(zeta)
+    o_next = zs_b.open_at(gzeta)
+    for o in (o_cs, o_w, o_z[:20], o_q, o_z[20:], o_next[:2], o_next[20:]):
+        ch.observe(o)
+    fri_alpha = ch.get(2)
+    fri = cd.fri([cs_b, wires_b, zs_b, q_b], zeta, fri_alpha)
+    fri_caps = []
+    for _ in range(d.num_fri_rounds):
+        cap = fri.commit_round()
+        fri_caps.append(cap)
+        ch.observe(cap)
+        fri.fold(ch.get(2))
+    fin = fri.final_poly()
+    ch.observe(fin)
+    pw = p.pow_grind(ch.state, ch.inp, d.proof_of_work_bits)
+    ch.observe([pw])
+    assert ch.get(1)[0] >> (64 - d.proof_of_work_bits) == 0
+    x_index = [ch.get(1)[0] % N for _ in range(d.num_query_rounds)]
+    blob = fri.query(x_index)
+    le = lambda arr: np.ascontiguousarray(np.asarray(arr, dtype="<u8")).tobytes()
+    by = le(wires_b.cap) + le(zs_b.cap) + le(q_b.cap)
+    by += le(o_cs) + le(o_w) + le(o_z[:2]) + le(o_next[:2]) + le(o_z[20:]) + le(o_next[20:]) + le(o_z[2:20]) + le(o_q)
+    by += b"".join(le(c) for c in fri_caps) + blob + le(fin) + le([pw]) + le([pis.size]) + le(pis)
+    assert by == op.to_bytes()
+    assert by == cd.prove(wires, pis).to_bytes()
+    assert cd.verify(by) == (True, "")
+    for h in (fri, q_b, zs_b, wires_b):
+        del h
+
+
 def test_prover_pool_matches_individual_proofs(gpu):
     # gl_prover_pool_*: one call, several proofs in flight on C++ threads (witness generation in HBM + prove per lane); every
     # proof equals the one produced alone on the default context, whatever lane and order it ran in
