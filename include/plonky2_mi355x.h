@@ -227,6 +227,10 @@ int gl_circuit_create_from_classes(gl_ctx* ctx, const gl_circuit_desc* desc, con
 int gl_circuit_from_host(gl_ctx* ctx, const gl_host_circuit* hc, gl_circuit** out);
 /* the wire classes of the host description, h_out[80][n] (gl_circuit_create_from_classes takes them) */
 int gl_host_circuit_wire_classes(const gl_host_circuit* hc, uint64_t* h_out);
+/* The description the circuit was built with, completed: for a circuit with lookups build() reads last_lu_row / last_lut_row /
+ * first_lut_row from the lookup selector columns (they are ProverOnlyCircuitData::lookup_rows in the reference and are not part of
+ * CommonCircuitData's bytes), checks any the caller named against them, and refuses a mismatch with GL_ERR_ARG. */
+int gl_circuit_description(const gl_circuit* c, gl_circuit_desc* out);
 int gl_circuit_digest(const gl_circuit* c, uint64_t h_out[4]);                 /* verifier_only.circuit_digest */
 int gl_circuit_constants_sigmas_cap(const gl_circuit* c, uint64_t* h_out);     /* [2^cap_height][4]            */
 const gl_batch* gl_circuit_constants_sigmas_batch(const gl_circuit* c);

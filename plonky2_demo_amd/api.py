@@ -598,6 +598,8 @@ class GenericCircuitData(_PhaseApi):
         h = ctypes.c_void_p()
         check(lib.gl_circuit_create(self.ctx.handle, ctypes.byref(desc), _p(cs), ctypes.byref(h)))
         self.handle = h.value
+        self.desc = type(desc)()                      # the completed description (lookup rows read from the selector columns)
+        check(lib.gl_circuit_description(self.handle, ctypes.byref(self.desc)))
 
     @property
     def circuit_digest(self):

@@ -144,6 +144,29 @@ extern "C" void gl_circuit_free(gl_circuit* c) {
     delete c;
 }
 
+// The lookup rows of a description are ProverOnlyCircuitData (lookup_rows, circuit_data.rs:335-360): CommonCircuitData's bytes do not carry
+// last_lu_row. The lookup SELECTOR columns do (gates/selectors.rs:50-103): LastLdc is 1 at last_lu_row only, the table's end selector at
+// last_lut_row only, InitSre at first_lut_row + 1 only. build() reads the rows from there and refuses a description that disagrees.
+static int lookup_rows_from_selectors(gl_circuit_desc& d, const uint64_t* h_constants) {
+    if (!d.lut_len) return GL_OK;
+    const size_t n = size_t(1) << d.degree_bits;
+    auto only_one = [&](unsigned sel, uint32_t& row) {
+        const uint64_t* col = h_constants + (size_t)(d.num_selectors + sel) * n;
+        size_t hits = 0;
+        for (size_t r = 0; r < n; r++) if (col[r] == 1) { row = (uint32_t)r; hits++; } else if (col[r] != 0) return false;
+        return hits == 1;
+    };
+    uint32_t lu = 0, lut = 0, init = 0;
+    GL_REQUIRE(d.num_lookup_selectors == glhost::LU_SEL_START_END + 1 && d.num_constants >= d.num_selectors + d.num_lookup_selectors && only_one(glhost::LU_SEL_LAST_LDC, lu) &&
+               only_one(glhost::LU_SEL_START_END, lut) && only_one(glhost::LU_SEL_INIT_SRE, init) && init >= 1, GL_ERR_ARG,
+               "lookup selector columns do not describe one table");
+    // a description read from common-data bytes has last_lu_row = 0 (unknown); any row it does name has to agree
+    GL_REQUIRE((!d.last_lu_row || d.last_lu_row == lu) && (!d.last_lut_row || d.last_lut_row == lut) && (!d.first_lut_row || d.first_lut_row == init - 1),
+               GL_ERR_ARG, "the description's lookup rows disagree with the lookup selector columns");
+    d.last_lu_row = lu; d.last_lut_row = lut; d.first_lut_row = init - 1;
+    return GL_OK;
+}
+
 int gl_sigmas_from_classes(gl_ctx* c, const uint64_t* d_classes, uint32_t lgn, uint32_t ncols, const uint64_t* h_k_is, gl_t* d_sigma);      // sigma.hip
 
 // the rest of the device half of build() once the constants || sigmas VALUE columns are in HBM (d_cs[num_constants + 80][n])
@@ -183,16 +206,23 @@ static int circuit_finish(gl_ctx* ctx, const gl_circuit_desc* desc, const gl_t* 
 }
 extern "C" int gl_circuit_create(gl_ctx* ctx, const gl_circuit_desc* desc, const uint64_t* h_cs, gl_circuit** out) {
     GL_REQUIRE(ctx && desc && h_cs && out, GL_ERR_ARG, "null argument");
-    GL_TRY(validate_desc(*desc));
+    GL_REQUIRE(desc->degree_bits >= 1 && desc->degree_bits <= 21 && desc->num_selectors <= 4, GL_ERR_ARG, "bad degree / selector count");
+    gl_circuit_desc d = *desc;
+    GL_TRY(lookup_rows_from_selectors(d, h_cs));
+    GL_TRY(validate_desc(d));
     GL_TRY(ctx->activate());
-    const size_t n = size_t(1) << desc->degree_bits, ncs = desc->num_constants + 80;
+    const size_t n = size_t(1) << d.degree_bits, ncs = d.num_constants + 80;
     DevBuf d_cs(ctx); GL_TRY(d_cs.alloc(ncs * n * sizeof(gl_t)));
     GL_TRY(gl_copy_h2d(ctx, d_cs.p, h_cs, ncs * n * sizeof(gl_t)));
-    return circuit_finish(ctx, desc, d_cs.as<gl_t>(), out);
+    return circuit_finish(ctx, &d, d_cs.as<gl_t>(), out);
 }
 // build() with the sigma polynomials computed on the device from the copy-constraint classes (sigma.hip)
 extern "C" int gl_circuit_create_from_classes(gl_ctx* ctx, const gl_circuit_desc* desc, const uint64_t* h_constants, const uint64_t* h_wire_classes, gl_circuit** out) {
     GL_REQUIRE(ctx && desc && h_constants && h_wire_classes && out, GL_ERR_ARG, "null argument");
+    GL_REQUIRE(desc->degree_bits >= 1 && desc->degree_bits <= 21 && desc->num_selectors <= 4, GL_ERR_ARG, "bad degree / selector count");
+    gl_circuit_desc dd = *desc;
+    GL_TRY(lookup_rows_from_selectors(dd, h_constants));
+    desc = &dd;
     GL_TRY(validate_desc(*desc));
     GL_TRY(ctx->activate());
     const size_t n = size_t(1) << desc->degree_bits, nc = desc->num_constants;
@@ -215,6 +245,11 @@ extern "C" int gl_circuit_from_host(gl_ctx* ctx, const gl_host_circuit* hc, gl_c
 extern "C" int gl_host_circuit_wire_classes(const gl_host_circuit* hc, uint64_t* h_out) {
     GL_REQUIRE(hc && h_out, GL_ERR_ARG, "null argument");
     memcpy(h_out, hc->hc.wire_class.data(), hc->hc.wire_class.size() * sizeof(uint64_t));
+    return GL_OK;
+}
+extern "C" int gl_circuit_description(const gl_circuit* c, gl_circuit_desc* out) {
+    GL_REQUIRE(c && out, GL_ERR_ARG, "null argument");
+    *out = c->desc;
     return GL_OK;
 }
 extern "C" int gl_circuit_digest(const gl_circuit* c, uint64_t h_out[4]) {

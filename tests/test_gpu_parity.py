@@ -905,6 +905,27 @@ def test_lookup_argument_circuits(gpu, orc, kind, param, inputs):
     assert zs_g[20:].any()
 
 
+def test_lookup_rows_come_from_the_selector_columns(gpu, orc):
+    # CommonCircuitData bytes do not hold last_lu_row (ProverOnlyCircuitData.lookup_rows, circuit_data.rs): a description read back from
+    # them builds the same circuit and proves the same bytes, because build() reads the rows from the lookup selector columns; a
+    # description that names a different row is refused, not proved wrongly
+    p, ctx = gpu
+    import copy
+    from plonky2_demo_amd import api
+    oc = orc.circuit_of_kind(8, 50, threads=8)
+    w = oc.witness(np.arange(3, 53, dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=9)
+    desc = oc.product_desc()
+    d2, _ = api.common_data_from_bytes(api.common_data_to_bytes(desc))
+    assert d2.last_lu_row == 0 and desc.last_lu_row != 0 and d2.last_lut_row == desc.last_lut_row
+    cd = p.GenericCircuitData(d2, oc.constants_sigmas())
+    assert cd.prove(w.wires(), w.public_inputs()).to_bytes() == w.prove(threads=8).to_bytes()
+    for field in ("last_lu_row", "last_lut_row", "first_lut_row"):
+        bad = copy.copy(desc)
+        setattr(bad, field, getattr(desc, field) + 1)
+        with pytest.raises(p.Plonky2Mi355xError, match="lookup"):
+            p.GenericCircuitData(bad, oc.constants_sigmas())
+
+
 def test_phase_api_on_a_lookup_circuit_with_an_external_transcript(gpu, orc):
     # the phase-level seam for a circuit WITH lookups: gl_partial_products_lookups / gl_quotient_polys_lookups take the delta challenges
     # ([betas | gammas | 4 drawn after them], prover.rs:166-184); openings in FriOpenings order with the lookup polynomials last in both
