@@ -15,7 +15,10 @@
 #include "gl64.cuh"
 
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ gl_t glx_mk64(uint32_t lo, uint32_t hi) { return ((gl_t)hi << 32) | lo; }
+// (hi:lo) as a register pair.  Written as a two-lane vector, not (hi << 32) | lo: the compiler re-associates x + ((hi << 32) | lo)
+// into (x + (hi << 32)) + lo -- two 64-bit adds and two zero registers instead of one add of the pair.
+typedef uint32_t glx_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gl_t glx_mk64(uint32_t lo, uint32_t hi) { glx_u32x2 v = {lo, hi}; return __builtin_bit_cast(gl_t, v); }
 // z + bit * EPS (mod 2^64) for bit in {0, 1}: one multiply-add, no 64-bit pair to build for the addend
 __device__ __forceinline__ gl_t glx_add_eps_if(gl_t z, uint32_t bit) {
     gl_t r;
@@ -79,22 +82,26 @@ __device__ __forceinline__ void glx_mul3(gl_t aA, gl_t bA, gl_t aB, gl_t bB, gl_
         : [w2A] "v"(w2A), [loA] "v"(loA), [w2B] "v"(w2B), [loB] "v"(loB), [w2C] "v"(w2C), [loC] "v"(loC));
     // y = z - hh (hh = w3 + cm) mod 2^64, borrow b.  The true value is y + (c - b) 2^64: c > b -> add EPS, b > c -> subtract EPS
     // (neither overflows: goldilocks_field.rs:355-369); both results are < p, with c = b the value y may still be >= p.
-    u32 y0A = (u32)zA, y1A = (u32)(zA >> 32), y0B = (u32)zB, y1B = (u32)(zB >> 32), y0C = (u32)zC, y1C = (u32)(zC >> 32);
+    // The halves of y are fresh outputs (not tied to z's): tied halves of a 64-bit pair cost two register copies per product.
+    u32 y0A, y1A, y0B, y1B, y0C, y1C;
     uint64_t bwA, bwB, bwC;
-    asm("v_subb_co_u32_e64 %[y0A], vcc, %[y0A], %[w3A], %[cmA]\n\t"
-        "v_subb_co_u32_e64 %[y0B], %[bwB], %[y0B], %[w3B], %[cmB]\n\t"
-        "v_subb_co_u32_e64 %[y0C], %[bwC], %[y0C], %[w3C], %[cmC]\n\t"
-        "v_subbrev_co_u32_e64 %[y1A], %[bwA], 0, %[y1A], vcc\n\t"
-        "v_subbrev_co_u32_e64 %[y1B], %[bwB], 0, %[y1B], %[bwB]\n\t"
-        "v_subbrev_co_u32_e64 %[y1C], %[bwC], 0, %[y1C], %[bwC]"
-        : [y0A] "+v"(y0A), [y1A] "+v"(y1A), [y0B] "+v"(y0B), [y1B] "+v"(y1B), [y0C] "+v"(y0C), [y1C] "+v"(y1C),
+    asm("v_subb_co_u32_e64 %[y0A], vcc, %[z0A], %[w3A], %[cmA]\n\t"
+        "v_subb_co_u32_e64 %[y0B], %[bwB], %[z0B], %[w3B], %[cmB]\n\t"
+        "v_subb_co_u32_e64 %[y0C], %[bwC], %[z0C], %[w3C], %[cmC]\n\t"
+        "v_subbrev_co_u32_e64 %[y1A], %[bwA], 0, %[z1A], vcc\n\t"
+        "v_subbrev_co_u32_e64 %[y1B], %[bwB], 0, %[z1B], %[bwB]\n\t"
+        "v_subbrev_co_u32_e64 %[y1C], %[bwC], 0, %[z1C], %[bwC]"
+        : [y0A] "=&v"(y0A), [y1A] "=&v"(y1A), [y0B] "=&v"(y0B), [y1B] "=&v"(y1B), [y0C] "=&v"(y0C), [y1C] "=&v"(y1C),
           [bwA] "=&s"(bwA), [bwB] "=&s"(bwB), [bwC] "=&s"(bwC)
-        : [w3A] "v"(w3A), [cmA] "s"(cmA), [w3B] "v"(w3B), [cmB] "s"(cmB), [w3C] "v"(w3C), [cmC] "s"(cmC)
+        : [z0A] "v"((u32)zA), [z1A] "v"((u32)(zA >> 32)), [z0B] "v"((u32)zB), [z1B] "v"((u32)(zB >> 32)), [z0C] "v"((u32)zC), [z1C] "v"((u32)(zC >> 32)),
+          [w3A] "v"(w3A), [cmA] "s"(cmA), [w3B] "v"(w3B), [cmB] "s"(cmB), [w3C] "v"(w3C), [cmC] "s"(cmC)
         : "vcc");
+    const gl_t yA = glx_mk64(y0A, y1A), yB = glx_mk64(y0B, y1B), yC = glx_mk64(y0C, y1C);
     u32 f0A, f1A, f0B, f1B, f0C, f1C;
     uint64_t tA, tB, tC;
     // N = b & ~c: subtract EPS.  P = c & ~b: add EPS.  CANON: y >= p and nothing subtracted: add EPS as well (= y - p mod 2^64).
-    // (f1:f0) = +EPS, -EPS (mod 2^64) or 0; the scalar unit combines the masks while the vector unit is busy elsewhere
+    // (f1:f0) = +EPS, -EPS (mod 2^64) or 0; the scalar unit combines the masks while the vector unit is busy elsewhere.  The sum
+    // y + f is one 64-bit add (v_lshl_add_u64), left to the compiler.
 #define GLX_MUL3_TAIL                                                     \
         "v_cndmask_b32_e64 %[f1A], 0, -1, %[tA]\n\t"                      \
         "v_cndmask_b32_e64 %[f1B], 0, -1, %[tB]\n\t"                      \
@@ -104,15 +111,8 @@ __device__ __forceinline__ void glx_mul3(gl_t aA, gl_t bA, gl_t aB, gl_t bB, gl_
         "v_cndmask_b32_e64 %[f0C], 0, -1, %[bwC]\n\t"                     \
         "v_sub_u32 %[f0A], %[f0A], %[f1A]\n\t"                            \
         "v_sub_u32 %[f0B], %[f0B], %[f1B]\n\t"                            \
-        "v_sub_u32 %[f0C], %[f0C], %[f1C]\n\t"                            \
-        "v_add_co_u32 %[y0A], vcc, %[y0A], %[f0A]\n\t"                    \
-        "v_add_co_u32_e64 %[y0B], %[tB], %[y0B], %[f0B]\n\t"              \
-        "v_add_co_u32_e64 %[y0C], %[tC], %[y0C], %[f0C]\n\t"              \
-        "v_addc_co_u32 %[y1A], vcc, %[y1A], %[f1A], vcc\n\t"              \
-        "v_addc_co_u32_e64 %[y1B], %[tB], %[y1B], %[f1B], %[tB]\n\t"      \
-        "v_addc_co_u32_e64 %[y1C], %[tC], %[y1C], %[f1C], %[tC]"
+        "v_sub_u32 %[f0C], %[f0C], %[f1C]"
     if constexpr (CANON) {
-        const gl_t yA = glx_mk64(y0A, y1A), yB = glx_mk64(y0B, y1B), yC = glx_mk64(y0C, y1C);
         uint64_t gA, gB, gC;
         asm("v_cmp_gt_u64_e64 %[gA], %[yA], %[pm1]\n\t"
             "v_cmp_gt_u64_e64 %[gB], %[yB], %[pm1]\n\t"
@@ -133,11 +133,10 @@ __device__ __forceinline__ void glx_mul3(gl_t aA, gl_t bA, gl_t aB, gl_t bB, gl_
             "s_or_b64 %[bwC], %[gC], %[bwC]\n\t"
             GLX_MUL3_TAIL
             : [f0A] "=&v"(f0A), [f1A] "=&v"(f1A), [f0B] "=&v"(f0B), [f1B] "=&v"(f1B), [f0C] "=&v"(f0C), [f1C] "=&v"(f1C),
-              [y0A] "+v"(y0A), [y1A] "+v"(y1A), [y0B] "+v"(y0B), [y1B] "+v"(y1B), [y0C] "+v"(y0C), [y1C] "+v"(y1C),
               [tA] "=&s"(tA), [tB] "=&s"(tB), [tC] "=&s"(tC), [gA] "+s"(gA), [gB] "+s"(gB), [gC] "+s"(gC),
               [bwA] "+s"(bwA), [bwB] "+s"(bwB), [bwC] "+s"(bwC)
             : [cA] "s"(cA), [cB] "s"(cB), [cC] "s"(cC)
-            : "vcc", "scc");
+            : "scc");
     } else {
         asm("s_andn2_b64 %[tA], %[bwA], %[cA]\n\t"
             "s_andn2_b64 %[tB], %[bwB], %[cB]\n\t"
@@ -147,13 +146,12 @@ __device__ __forceinline__ void glx_mul3(gl_t aA, gl_t bA, gl_t aB, gl_t bB, gl_
             "s_andn2_b64 %[bwC], %[cC], %[bwC]\n\t"
             GLX_MUL3_TAIL
             : [f0A] "=&v"(f0A), [f1A] "=&v"(f1A), [f0B] "=&v"(f0B), [f1B] "=&v"(f1B), [f0C] "=&v"(f0C), [f1C] "=&v"(f1C),
-              [y0A] "+v"(y0A), [y1A] "+v"(y1A), [y0B] "+v"(y0B), [y1B] "+v"(y1B), [y0C] "+v"(y0C), [y1C] "+v"(y1C),
               [tA] "=&s"(tA), [tB] "=&s"(tB), [tC] "=&s"(tC), [bwA] "+s"(bwA), [bwB] "+s"(bwB), [bwC] "+s"(bwC)
             : [cA] "s"(cA), [cB] "s"(cB), [cC] "s"(cC)
-            : "vcc", "scc");
+            : "scc");
     }
 #undef GLX_MUL3_TAIL
-    rA = glx_mk64(y0A, y1A); rB = glx_mk64(y0B, y1B); rC = glx_mk64(y0C, y1C);
+    rA = yA + glx_mk64(f0A, f1A); rB = yB + glx_mk64(f0B, f1B); rC = yC + glx_mk64(f0C, f1C);
 }
 
 // One product (the same arithmetic, with the wait states the lone carry chains need): for counts that are not multiples of three
