@@ -64,7 +64,7 @@ typedef struct gl_proof gl_proof;      /* ProofWithPublicInputs + the prover's i
  * 380-440) besides the constants/sigma value columns.  Gate types: 0 Noop, 1 Constant, 2 PublicInput,
  * 3 Arithmetic(20 ops), 4 Poseidon -- the gate set of the matmul demo circuit -- and 5 BaseSumGate<2> with the 63 limbs
  * of BaseSumGate::new_from_config (gates/base_sum.rs:31-35; range_check / split_le), 6 LookupGate and 7 LookupTableGate
- * (the lookup argument: fields at the end of this struct; phase API: the *_lookups variants); `gate_types` is the list
+ * (the lookup argument, several tables: fields at the end of this struct; phase API: the *_lookups variants); `gate_types` is the list
  * `common_data.gates` (sorted by degree, id) and the group arrays are `selectors_info`
  * (plonky2/src/gates/selectors.rs:17-26). */
 typedef struct gl_circuit_desc {
@@ -79,20 +79,28 @@ typedef struct gl_circuit_desc {
     uint32_t num_fri_rounds;           /* reduction_arity_bits.len()                                */
     uint32_t fri_arity_bits[8];
     uint32_t num_public_inputs;
-    uint32_t num_gates;
-    uint8_t gate_types[8];
-    uint32_t gate_selector_index[8];
-    uint32_t gate_group_start[8], gate_group_end[8];
+    uint32_t num_gates;                /* <= GL_MAX_GATES                                           */
+    uint8_t gate_types[16];
+    uint8_t gate_luts[16];             /* the table (index into the lists below) of a LookupGate / LookupTableGate, else 0 */
+    uint32_t gate_selector_index[16];
+    uint32_t gate_group_start[16], gate_group_end[16];
     uint64_t k_is[80];                 /* coset shifts 7^j (field/src/cosets.rs:9-24)               */
-    /* ---- lookup argument (ONE lookup table; all zero without lookups).  Gate types 6 = LookupGate (40 slots), 7 = LookupTableGate
-     * (26 slots) (gates/lookup.rs, gates/lookup_table.rs); `num_constants` counts the lookup selector columns, which sit between the
-     * gate selectors and the gates' constants (circuit_builder.rs:991-1004) ---- */
+    /* ---- lookup argument (up to GL_MAX_LUTS tables; all zero without lookups).  Gate types 6 = LookupGate (40 slots), 7 =
+     * LookupTableGate (26 slots) (gates/lookup.rs, gates/lookup_table.rs): one of each PER TABLE in `gate_types`, told apart by
+     * `gate_luts`; `num_constants` counts the lookup selector columns, which sit between the gate selectors and the gates' constants
+     * (circuit_builder.rs:991-1004) ---- */
     uint32_t num_lookup_polys;         /* per challenge: 1 RE + ceil(40 / 7) partial SLDC = 7 (circuit_builder.rs:1079-1085)     */
-    uint32_t num_lookup_selectors;     /* TransSre, TransLdc, InitSre, LastLdc + one end selector per table = 5                */
-    uint32_t last_lu_row, last_lut_row, first_lut_row;   /* LookupWire (circuit_builder.rs:73-85): the gate rows are upside down */
-    uint32_t lut_len;                  /* entries of the table, <= GL_MAX_LUT_ENTRIES                                          */
-    uint16_t lut[2 * 1024];            /* (input, output) pairs (gates/lookup_table.rs:22)                                     */
+    uint32_t num_lookup_selectors;     /* TransSre, TransLdc, InitSre, LastLdc + one end selector per table = 4 + num_luts     */
+    uint32_t num_luts;                 /* common_data.luts.len(); every table has lookups (gadgets/lookup.rs:79-84)            */
+    /* LookupWire per table (circuit_builder.rs:73-85; the gate rows are upside down: last_lu_row < last_lut_row <= first_lut_row).
+     * ProverOnlyCircuitData: a description read from CommonCircuitData bytes has last_lu_row = 0, and build() fills the rows in
+     * from the lookup selector columns (gl_circuit_description returns them). */
+    uint32_t last_lu_row[4], last_lut_row[4], first_lut_row[4];
+    uint32_t lut_len[4];               /* entries per table; their sum <= GL_MAX_LUT_ENTRIES                                   */
+    uint16_t lut[2 * 1024];            /* (input, output) pairs (gates/lookup_table.rs:22), the tables one after the other     */
 } gl_circuit_desc;
+#define GL_MAX_GATES 16
+#define GL_MAX_LUTS 4
 #define GL_MAX_LUT_ENTRIES 1024
 
 /* ---- context ------------------------------------------------------------------------------------ */

@@ -44,7 +44,7 @@ struct CommonData {
     size_t num_gate_constraints = 0, num_constants = 0, num_public_inputs = 0, num_partial_products = 0;
     size_t quotient_degree_factor = 8;
     size_t num_lookup_polys = 0, num_lookup_selectors = 0;      // circuit_data.rs:376-381: per challenge 1 RE + ceil(40 / 7) partial SLDC polynomials
-    size_t last_lut_row = 0;                                    // LookupTableGate's third field (lookup_table.rs:31-32): the first LookupTableGate row
+    std::vector<size_t> last_lut_rows;                          // per table: LookupTableGate's third field (lookup_table.rs:31-32), its lowest row
     std::vector<std::vector<std::pair<uint16_t, uint16_t>>> luts;   // the lookup tables: (input, output) pairs
     std::vector<u64> k_is;
     std::vector<unsigned> fri_reduction_arity_bits;
@@ -85,7 +85,7 @@ struct CircuitData {
 // ---- the builder -------------------------------------------------------------------------------------
 struct CircuitBuilder {
     CircuitConfig config;
-    struct GateInstance { GateType type; u64 constants[2]; };
+    struct GateInstance { GateType type; u64 constants[2]; size_t lut; };       // lut: the table of a LookupGate / LookupTableGate
     std::vector<GateInstance> gate_instances;
     std::vector<Target> public_inputs;
     size_t virtual_target_index = 0;
@@ -101,10 +101,10 @@ struct CircuitBuilder {
     std::map<std::tuple<u64, u64, TargetKey, TargetKey, TargetKey>, Target> arithmetic_results;
 
     Target add_virtual_target() { return Target::virt(virtual_target_index++); }
-    size_t add_gate(GateType t, u64 c0 = 0, u64 c1 = 0) {        // circuit_builder.rs:353-388
+    size_t add_gate(GateType t, u64 c0 = 0, u64 c1 = 0, size_t lut = 0) {        // circuit_builder.rs:353-388
         size_t row = gate_instances.size();
         if (t == GATE_CONSTANT) for (size_t i = 0; i < config.num_constants; i++) constant_generators.push_back({row, i, i});
-        gate_instances.push_back({t, {c0, c1}});
+        gate_instances.push_back({t, {c0, c1}, lut});
         return row;
     }
     bool record_copies = true;          // false for a verifier-only build (CommonData without sigmas / commitment)
@@ -191,12 +191,11 @@ struct CircuitBuilder {
         auto it = gate_slots.find(key);
         size_t row, slot;
         if (it != gate_slots.end()) { row = it->second.first; slot = it->second.second; }
-        else { row = add_gate(t); slot = 0; }
+        else { row = add_gate(t, 0, 0, (t == GATE_LOOKUP || t == GATE_LOOKUP_TABLE) ? (size_t)param : 0); slot = 0; }
         if (slot == num_ops - 1) gate_slots.erase(key); else gate_slots[key] = {row, slot + 1};
         return {row, slot};
     }
     void add_all_lookups() {                                                      // gadgets/lookup.rs:79-125
-        assert(luts.size() <= 1 && "this restatement places ONE lookup table (the gate order of several depends on their Debug strings)");
         for (size_t li = 0; li < luts.size(); li++) {
             assert(!lut_to_lookups[li].empty() && "LUT is unused");
             const size_t last_lu_gate = gate_instances.size();
@@ -208,7 +207,7 @@ struct CircuitBuilder {
             }
             const size_t last_lut_gate = gate_instances.size();
             const size_t num_lut_rows = (luts[li].size() - 1) / LOOKUP_TABLE_SLOTS + 1;
-            for (size_t c = 0; c < LOOKUP_TABLE_SLOTS * num_lut_rows; c++) (void)find_slot(GATE_LOOKUP_TABLE, 0, LOOKUP_TABLE_SLOTS);
+            for (size_t c = 0; c < LOOKUP_TABLE_SLOTS * num_lut_rows; c++) (void)find_slot(GATE_LOOKUP_TABLE, (u64)li, LOOKUP_TABLE_SLOTS);
             const size_t first_lut_gate = gate_instances.size() - 1;
             add_gate(GATE_NOOP);          // the row after the table is all zeros: initial constraints become a zero check
             lookup_rows.push_back({last_lu_gate, last_lut_gate, first_lut_gate});
@@ -295,14 +294,35 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
     cm.fri_reduction_arity_bits = fri_reduction_arity_bits(cfg, degree_bits);
     cm.quotient_degree_factor = cfg.max_quotient_degree_factor;
 
-    // gates sorted by (degree, id) (:984-986)
-    std::vector<GateType> gates;
+    // gates sorted by (degree, id) (:984-986).  A LookupGate / LookupTableGate is a different gate per table: its id is the Debug string of
+    // the struct, table included (lookup.rs:55-57, lookup_table.rs:66-68), so the order of several tables' gates is the text order of
+    // "[(0, 7), (1, 12), ...]" and, for two LookupTableGates over equal tables, of the decimal last_lut_row
+    struct Kind { GateType type; size_t lut; std::string id; };
+    std::vector<Kind> kinds;
+    auto lut_text = [&](size_t li) {
+        std::string t = "[";
+        for (size_t e = 0; e < b.luts[li].size(); e++)
+            t += (e ? ", (" : "(") + std::to_string(b.luts[li][e].first) + ", " + std::to_string(b.luts[li][e].second) + ")";
+        return t + "]";
+    };
     for (int g = 0; g < GATE_NUM_TYPES; g++)
-        for (auto& gi : b.gate_instances) if (gi.type == (GateType)g) { gates.push_back((GateType)g); break; }
-    std::sort(gates.begin(), gates.end(), [](GateType x, GateType y) {
-        return std::make_pair(gate_degree(x), gate_id(x)) < std::make_pair(gate_degree(y), gate_id(y)); });
-    // selector_polynomials(gates, instances, max_degree = quotient_degree_factor + 1) (selectors.rs:110-185)
+        for (size_t li = 0; li < std::max<size_t>(b.luts.size(), 1); li++) {
+            const bool per_table = g == GATE_LOOKUP || g == GATE_LOOKUP_TABLE;
+            if (!per_table && li) break;
+            bool used = false;
+            for (auto& gi : b.gate_instances) if (gi.type == (GateType)g && (!per_table || gi.lut == li)) { used = true; break; }
+            if (!used) continue;
+            std::string id = gate_id((GateType)g);
+            if (g == GATE_LOOKUP) id += lut_text(li).substr(1) + " }";              // gate_id() ends with "lut: ["
+            if (g == GATE_LOOKUP_TABLE) id += lut_text(li).substr(1) + ", last_lut_row: " + std::to_string(b.lookup_rows[li].last_lut_gate) + " }";
+            kinds.push_back({(GateType)g, li, id});
+        }
+    std::sort(kinds.begin(), kinds.end(), [](const Kind& x, const Kind& y) {
+        return std::make_pair(gate_degree(x.type), x.id) < std::make_pair(gate_degree(y.type), y.id); });
+    std::vector<GateType> gates;
     SelectorsInfo& si = cm.selectors;
+    for (auto& k : kinds) { gates.push_back(k.type); si.gate_luts.push_back(k.lut); }
+    // selector_polynomials(gates, instances, max_degree = quotient_degree_factor + 1) (selectors.rs:110-185)
     si.gates = gates;
     const size_t max_degree = cm.quotient_degree_factor + 1, num_gates = gates.size();
     const size_t max_gate_degree = gate_degree(gates.back());
@@ -323,7 +343,7 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
     }
     std::vector<std::vector<u64>> constant_vecs(si.groups.size(), std::vector<u64>(degree));
     for (size_t j = 0; j < degree; j++) {
-        size_t i = si.gate_index(b.gate_instances[j].type), gr = si.selector_indices[i];
+        size_t i = si.gate_index(b.gate_instances[j].type, b.gate_instances[j].lut), gr = si.selector_indices[i];
         for (size_t g = 0; g < si.groups.size(); g++) constant_vecs[g][j] = (si.groups.size() == 1 || g == gr) ? i : UNUSED_SELECTOR;
     }
     // lookup selectors (circuit_builder.rs:991-1002; gates/selectors.rs:50-103): TransSre, TransLdc, InitSre, LastLdc, then one "end"
@@ -342,7 +362,7 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
         for (auto& v : ls) constant_vecs.push_back(v);
         cm.num_lookup_polys = (LOOKUP_SLOTS + (cfg.max_quotient_degree_factor - 1) - 1) / (cfg.max_quotient_degree_factor - 1) + 1;     // :1079-1085
         cm.luts = b.luts;
-        cm.last_lut_row = b.lookup_rows[0].last_lut_gate;
+        for (auto& lr : b.lookup_rows) cm.last_lut_rows.push_back(lr.last_lut_gate);
     }
     // constant_polys (:822-843): max_constants over gate types used
     size_t max_constants = 0;
@@ -489,6 +509,23 @@ static inline CircuitData build_test_circuit(int kind, size_t param, unsigned th
         for (size_t i = 0; i < param; i++) { Target t = b.add_virtual_target(); ins.push_back(t); outs.push_back(b.add_lookup_from_index(t, ti)); }
         b.public_inputs = ins;
         b.public_inputs.insert(b.public_inputs.end(), outs.begin(), outs.end());
+        cd.a_targets = ins;
+    } else if (kind == 10 || kind == 11 || kind == 12) {
+        // SEVERAL tables.  kind 10: plonky2/src/lookup_test.rs:107-187 (test_two_luts): two 256-entry tables, `param` lookups in each, and
+        // the sum of the two first outputs through an ArithmeticGate.  kind 11: :191-271 (test_different_inputs): an 8-entry table on
+        // inputs 2..9 next to a 256-entry one.  kind 12: :366-440 (test_same_luts): the same table added twice is stored once.
+        // Inputs: `param` values for the first table, then `param` for the second.  Public inputs: inputs, outputs, (kind 10) the sum.
+        std::vector<std::pair<uint16_t, uint16_t>> t0, t1;
+        for (unsigned i = 0; i < 256; i++) t1.push_back({(uint16_t)i, (uint16_t)((3 * i * i + 5 * i + 7) % 256)});
+        if (kind == 10) for (unsigned i = 0; i < 256; i++) t0.push_back({(uint16_t)i, (uint16_t)((7 * i + 1) % 256)});
+        else if (kind == 11) for (unsigned i = 2; i < 10; i++) t0.push_back({(uint16_t)i, (uint16_t)(i * i + 1)});
+        else t0 = t1;
+        const size_t i0 = b.add_lookup_table_from_pairs(t0), i1 = b.add_lookup_table_from_pairs(t1);
+        std::vector<Target> ins, outs;
+        for (size_t i = 0; i < 2 * param; i++) { Target t = b.add_virtual_target(); ins.push_back(t); outs.push_back(b.add_lookup_from_index(t, i < param ? i0 : i1)); }
+        b.public_inputs = ins;
+        b.public_inputs.insert(b.public_inputs.end(), outs.begin(), outs.end());
+        if (kind == 10) b.public_inputs.push_back(b.add_t(outs[0], outs[param]));
         cd.a_targets = ins;
     } else if (kind == 7) {
         // plonky2/examples/range_check.rs:20-24: the value is a public input and is range-checked to `param` (6) bits

@@ -172,11 +172,15 @@ static inline void eval_poseidon(const K* w, K* out) {                          
 // Selector bookkeeping (selectors.rs:110-185)
 struct SelectorsInfo {
     std::vector<GateType> gates;                 // sorted by (degree, id): circuit_builder.rs:984-986
+    std::vector<size_t> gate_luts;               // per gate: the lookup table of a LookupGate / LookupTableGate (else 0)
     std::vector<size_t> selector_indices;        // per gate: which selector polynomial
     std::vector<std::pair<size_t, size_t>> groups;   // [start, end) ranges of gate indices
     size_t num_selectors() const { return groups.size(); }
     size_t num_lookup_selectors = 0;             // lookup selector columns between the gate selectors and the gates' constants
-    size_t gate_index(GateType g) const { for (size_t i = 0; i < gates.size(); i++) if (gates[i] == g) return i; assert(false); return 0; }
+    size_t gate_index(GateType g, size_t lut = 0) const {
+        for (size_t i = 0; i < gates.size(); i++) if (gates[i] == g && (gate_luts.empty() || gate_luts[i] == lut)) return i;
+        assert(false); return 0;
+    }
 };
 
 template <class K>

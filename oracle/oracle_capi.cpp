@@ -283,15 +283,17 @@ static void sink_common(ByteSink& o, const CommonData& cm) {
     o.usize(cm.fri_reduction_arity_bits.size()); for (auto a : cm.fri_reduction_arity_bits) o.usize(a);
     o.usize(cm.degree_bits); o.byte(0);
     o.usize(cm.selectors.gates.size());
-    for (GateType g : cm.selectors.gates) {
+    for (size_t gi = 0; gi < cm.selectors.gates.size(); gi++) {
+        const GateType g = cm.selectors.gates[gi];
+        const size_t li = cm.selectors.gate_luts.empty() ? 0 : cm.selectors.gate_luts[gi];
         switch (g) {
             case GATE_ARITHMETIC: o.word32(0); o.usize(c.num_routed_wires / 4); break;     // ArithmeticGate::new_from_config: num_ops = routed / 4
             case GATE_CONSTANT: o.word32(3); o.usize(c.num_constants); break;
             case GATE_NOOP: o.word32(9); break;
             case GATE_POSEIDON: o.word32(11); break;
             case GATE_BASE_SUM: o.word32(2); o.usize(BASE_SUM_LIMBS); break;              // BaseSumGate<2>: write_usize(num_limbs) (base_sum.rs:53-55)
-            case GATE_LOOKUP: o.word32(6); o.usize(LOOKUP_SLOTS); sink_lut(o, cm.luts[0]); break;                    // lookup.rs:59-62
-            case GATE_LOOKUP_TABLE: o.word32(7); o.usize(LOOKUP_TABLE_SLOTS); sink_lut(o, cm.luts[0]); o.usize(cm.last_lut_row); break;   // lookup_table.rs:70-74
+            case GATE_LOOKUP: o.word32(6); o.usize(LOOKUP_SLOTS); sink_lut(o, cm.luts[li]); break;                    // lookup.rs:59-62
+            case GATE_LOOKUP_TABLE: o.word32(7); o.usize(LOOKUP_TABLE_SLOTS); sink_lut(o, cm.luts[li]); o.usize(cm.last_lut_rows[li]); break;   // lookup_table.rs:70-74
             default: o.word32(12); break;                                                  // PublicInputGate
         }
     }
@@ -329,16 +331,22 @@ void orc_circuit_info(const void* c, u64* out) {
                  cd->arith_ops.size(), cd->poseidon_rows.size()};
     memcpy(out, v, sizeof v);
 }
-// lookup data of a circuit: out6 = [num_lookup_polys, num_lookup_selectors, last_lu_row, last_lut_row, first_lut_row, lut_len]; lut (may be
-// null) receives the (input, output) pairs of the one table
-void orc_circuit_lookup_info(const void* c, u64* out6, uint16_t* lut) {
+// lookup data of a circuit: out3 = [num_lookup_polys, num_lookup_selectors, num_luts]; per table t: rows[4 t ..] = [last_lu_row, last_lut_row,
+// first_lut_row, entries]; lut (may be null) receives the (input, output) pairs of all tables, one after the other; gate_luts (may be null):
+// per gate of the sorted gate list, the table of a LookupGate / LookupTableGate (else 0)
+void orc_circuit_lookup_info(const void* c, u64* out3, u64* rows, uint16_t* lut, uint8_t* gate_luts) {
     const CircuitData* cd = (const CircuitData*)c;
     const CommonData& cm = cd->common;
-    u64 v[6] = {cm.num_lookup_polys, cm.num_lookup_selectors, 0, 0, 0, cm.luts.empty() ? 0 : cm.luts[0].size()};
-    if (!cd->lookup_rows.empty()) { v[2] = cd->lookup_rows[0].last_lu_gate; v[3] = cd->lookup_rows[0].last_lut_gate; v[4] = cd->lookup_rows[0].first_lut_gate; }
-    else if (!cm.luts.empty()) v[3] = cm.last_lut_row;
-    memcpy(out6, v, sizeof v);
-    if (lut && !cm.luts.empty()) for (size_t i = 0; i < cm.luts[0].size(); i++) { lut[2 * i] = cm.luts[0][i].first; lut[2 * i + 1] = cm.luts[0][i].second; }
+    out3[0] = cm.num_lookup_polys; out3[1] = cm.num_lookup_selectors; out3[2] = cm.luts.size();
+    size_t off = 0;
+    for (size_t t = 0; t < cm.luts.size(); t++) {
+        rows[4 * t] = rows[4 * t + 2] = 0;
+        rows[4 * t + 1] = cm.last_lut_rows[t];
+        if (t < cd->lookup_rows.size()) { rows[4 * t] = cd->lookup_rows[t].last_lu_gate; rows[4 * t + 1] = cd->lookup_rows[t].last_lut_gate; rows[4 * t + 2] = cd->lookup_rows[t].first_lut_gate; }
+        rows[4 * t + 3] = cm.luts[t].size();
+        if (lut) for (auto& e : cm.luts[t]) { lut[2 * off] = e.first; lut[2 * off + 1] = e.second; off++; }
+    }
+    if (gate_luts) for (size_t i = 0; i < cm.selectors.gates.size(); i++) gate_luts[i] = (uint8_t)(cm.selectors.gate_luts.empty() ? 0 : cm.selectors.gate_luts[i]);
 }
 void orc_circuit_digest(const void* c, u64* out4) { for (int i = 0; i < 4; i++) out4[i] = canon(((const CircuitData*)c)->circuit_digest.e[i]); }
 void orc_circuit_cs_cap(const void* c, u64* out) { write_digests(((const CircuitData*)c)->constants_sigmas_commitment.tree.cap(), out); }

@@ -151,11 +151,17 @@ class CircuitDesc(ctypes.Structure):
         ("num_selectors", c_u32), ("num_challenges", c_u32), ("quotient_degree_factor", c_u32),
         ("rate_bits", c_u32), ("cap_height", c_u32), ("proof_of_work_bits", c_u32), ("num_query_rounds", c_u32),
         ("num_fri_rounds", c_u32), ("fri_arity_bits", c_u32 * 8), ("num_public_inputs", c_u32), ("num_gates", c_u32),
-        ("gate_types", ctypes.c_uint8 * 8), ("gate_selector_index", c_u32 * 8),
-        ("gate_group_start", c_u32 * 8), ("gate_group_end", c_u32 * 8), ("k_is", c_u64 * 80),
-        ("num_lookup_polys", c_u32), ("num_lookup_selectors", c_u32), ("last_lu_row", c_u32), ("last_lut_row", c_u32), ("first_lut_row", c_u32),
-        ("lut_len", c_u32), ("lut", ctypes.c_uint16 * 2048),
+        ("gate_types", ctypes.c_uint8 * 16), ("gate_luts", ctypes.c_uint8 * 16), ("gate_selector_index", c_u32 * 16),
+        ("gate_group_start", c_u32 * 16), ("gate_group_end", c_u32 * 16), ("k_is", c_u64 * 80),
+        ("num_lookup_polys", c_u32), ("num_lookup_selectors", c_u32), ("num_luts", c_u32),
+        ("last_lu_row", c_u32 * 4), ("last_lut_row", c_u32 * 4), ("first_lut_row", c_u32 * 4), ("lut_len", c_u32 * 4),
+        ("lut", ctypes.c_uint16 * 2048),
     ]
+
+    def lookup_table(self, t):
+        """Table t as a list of (input, output) pairs: `lut` holds the tables one after the other."""
+        off = sum(self.lut_len[i] for i in range(t))
+        return [(self.lut[2 * (off + k)], self.lut[2 * (off + k) + 1]) for k in range(self.lut_len[t])]
 
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)   # AttributeError here = the .so does not export a declared symbol

@@ -33,6 +33,40 @@ enum { LU_SEL_TRANS_SRE = 0, LU_SEL_TRANS_LDC = 1, LU_SEL_INIT_SRE = 2, LU_SEL_L
 enum { BASE_SUM_LIMBS = 63 };      // BaseSumGate::<2>::new_from_config (gates/base_sum.rs:31-35): wire 0 = sum, wires 1..=63 = limbs
 static const uint64_t UNUSED_SELECTOR = 0xFFFFFFFFull;        // gates/selectors.rs:14
 
+// ---- lookup tables of a description: `lut` holds the tables one after the other ----
+inline uint32_t lut_offset(const gl_circuit_desc& d, unsigned t) { uint32_t o = 0; for (unsigned i = 0; i < t && i < GL_MAX_LUTS; i++) o += d.lut_len[i]; return o; }
+inline uint32_t lut_rows(const gl_circuit_desc& d, unsigned t) { return (d.lut_len[t] + LOOKUP_TABLE_SLOTS - 1) / LOOKUP_TABLE_SLOTS; }
+// the counts every consumer of a description relies on before it indexes lut / lut_len / the per-table rows; nullptr = fine
+inline const char* lookup_shape_error(const gl_circuit_desc& d) {
+    if (d.num_luts == 0) {
+        if (d.num_lookup_polys || d.num_lookup_selectors) return "lookup polynomials / selectors without a lookup table";
+        for (unsigned g = 0; g < d.num_gates && g < GL_MAX_GATES; g++)
+            if (d.gate_types[g] == G_LOOKUP || d.gate_types[g] == G_LOOKUP_TABLE) return "lookup gates without a lookup table";
+        return nullptr;
+    }
+    if (d.num_luts > GL_MAX_LUTS) return "more than GL_MAX_LUTS lookup tables";
+    if (d.num_lookup_polys != 7 || d.num_lookup_selectors != LU_SEL_START_END + d.num_luts)
+        return "lookups: 7 lookup polynomials and 4 + num_luts lookup selectors per challenge";
+    uint32_t total = 0;
+    for (unsigned t = 0; t < d.num_luts; t++) {
+        if (d.lut_len[t] < 1 || d.lut_len[t] > GL_MAX_LUT_ENTRIES) return "a lookup table needs 1 .. GL_MAX_LUT_ENTRIES entries";
+        total += d.lut_len[t];
+    }
+    if (total > GL_MAX_LUT_ENTRIES) return "the lookup tables together exceed GL_MAX_LUT_ENTRIES entries";
+    for (unsigned g = 0; g < d.num_gates && g < GL_MAX_GATES; g++)
+        if ((d.gate_types[g] == G_LOOKUP || d.gate_types[g] == G_LOOKUP_TABLE) ? d.gate_luts[g] >= d.num_luts : d.gate_luts[g] != 0) return "bad gate_luts";
+    return nullptr;
+}
+// get_lut_poly(common_data, t, deltas, 26 * rows).eval(delta) (vanishing_poly.rs:31-49): the table's combos inp + b out, zero-padded to
+// whole LookupTableGate rows and REVERSED, as coefficients of a polynomial at the delta challenge (Horner from combo_0)
+inline gl_t lut_poly_at_delta(const gl_circuit_desc& d, unsigned t, gl_t b, gl_t delta) {
+    const uint16_t* lut = d.lut + 2 * (size_t)lut_offset(d, t);
+    const size_t deg = (size_t)lut_rows(d, t) * LOOKUP_TABLE_SLOTS;
+    gl_t f = 0;
+    for (size_t k = 0; k < deg; k++) f = gl_add(gl_mul(f, delta), k < d.lut_len[t] ? gl_add((gl_t)lut[2 * k], gl_mul(b, (gl_t)lut[2 * k + 1])) : (gl_t)0);
+    return gl_canon(f);
+}
+
 // PoseidonGate wire layout (gates/poseidon.rs:36-96)
 enum { PW_INPUT = 0, PW_OUTPUT = 12, PW_SWAP = 24, PW_DELTA = 25, PW_FULL0 = 29, PW_PARTIAL = 65, PW_FULL1 = 87, PW_END = 135 };
 

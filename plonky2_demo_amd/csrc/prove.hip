@@ -114,22 +114,20 @@ static int validate_desc(const gl_circuit_desc& d) {
                "only standard_recursion_config (135 wires, 80 routed, 2 challenges, quotient factor 8) is supported");
     GL_REQUIRE(d.rate_bits == 3, GL_ERR_UNSUPPORTED, "rate_bits must equal log2(quotient_degree_factor) = 3 (prover.rs:596-608 step = 1)");
     GL_REQUIRE(d.cap_height <= d.degree_bits + d.rate_bits && d.degree_bits >= 1 && d.degree_bits + d.rate_bits <= 24, GL_ERR_ARG, "bad degree / cap height");
-    GL_REQUIRE((d.num_lookup_polys == 0 && d.num_lookup_selectors == 0 && d.lut_len == 0) ||
-               (d.num_lookup_polys == 7 && d.num_lookup_selectors == 5 && d.lut_len >= 1 && d.lut_len <= GL_MAX_LUT_ENTRIES), GL_ERR_UNSUPPORTED,
-               "lookups: one table of at most 1024 entries, 7 lookup polynomials and 5 lookup selectors per challenge");
-    if (d.lut_len) {
-        const uint32_t nrows = 1u << d.degree_bits, lut_rows = (d.lut_len + glhost::LOOKUP_TABLE_SLOTS - 1) / glhost::LOOKUP_TABLE_SLOTS;
-        GL_REQUIRE(d.last_lu_row < d.last_lut_row && d.last_lut_row <= d.first_lut_row && d.first_lut_row + 1 < nrows &&
-                   d.first_lut_row - d.last_lut_row + 1 == lut_rows, GL_ERR_ARG, "bad lookup rows");
-    }
-    GL_REQUIRE(d.num_gates >= 1 && d.num_gates <= 8 && d.num_selectors >= 1 && d.num_selectors <= 4 && d.num_constants == d.num_selectors + d.num_lookup_selectors + 2, GL_ERR_ARG, "bad gate / selector description");
+    GL_REQUIRE(d.num_gates >= 1 && d.num_gates <= GL_MAX_GATES && d.num_selectors >= 1 && d.num_selectors <= 4, GL_ERR_ARG, "bad gate / selector count");
+    { const char* why = glhost::lookup_shape_error(d); GL_REQUIRE(!why, GL_ERR_UNSUPPORTED, why); }
+    const uint32_t nrows = 1u << d.degree_bits;
+    for (unsigned t = 0; t < d.num_luts; t++)
+        GL_REQUIRE(d.last_lu_row[t] < d.last_lut_row[t] && d.last_lut_row[t] <= d.first_lut_row[t] && d.first_lut_row[t] + 1 < nrows &&
+                   d.first_lut_row[t] - d.last_lut_row[t] + 1 == glhost::lut_rows(d, t) && (t == 0 || d.last_lu_row[t] > d.first_lut_row[t - 1] + 1),
+                   GL_ERR_ARG, "bad lookup rows");
+    GL_REQUIRE(d.num_constants == d.num_selectors + d.num_lookup_selectors + 2, GL_ERR_ARG, "bad gate / selector description");
     GL_REQUIRE(d.num_fri_rounds <= 8 && d.num_query_rounds >= 1 && d.num_query_rounds <= 256 && d.proof_of_work_bits <= 40, GL_ERR_ARG, "bad FRI parameters");
     unsigned tot = 0;
     for (unsigned r = 0; r < d.num_fri_rounds; r++) { GL_REQUIRE(d.fri_arity_bits[r] == 4, GL_ERR_UNSUPPORTED, "FRI arity must be 16"); tot += 4; }
     GL_REQUIRE(tot <= d.degree_bits && d.degree_bits + d.rate_bits >= tot + d.cap_height, GL_ERR_ARG, "FRI total reduction arity is too large");   // circuit_builder.rs:977-980
     for (unsigned g = 0; g < d.num_gates; g++) {
         GL_REQUIRE(d.gate_types[g] <= glhost::G_LOOKUP_TABLE, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable}");
-        GL_REQUIRE((d.gate_types[g] != glhost::G_LOOKUP && d.gate_types[g] != glhost::G_LOOKUP_TABLE) || d.lut_len, GL_ERR_ARG, "lookup gates without a lookup table");
         GL_REQUIRE(d.gate_selector_index[g] < d.num_selectors && d.gate_group_start[g] <= g && g < d.gate_group_end[g] && d.gate_group_end[g] <= d.num_gates, GL_ERR_ARG, "bad selector group");
     }
     return GL_OK;
@@ -145,25 +143,33 @@ extern "C" void gl_circuit_free(gl_circuit* c) {
 }
 
 // The lookup rows of a description are ProverOnlyCircuitData (lookup_rows, circuit_data.rs:335-360): CommonCircuitData's bytes do not carry
-// last_lu_row. The lookup SELECTOR columns do (gates/selectors.rs:50-103): LastLdc is 1 at last_lu_row only, the table's end selector at
-// last_lut_row only, InitSre at first_lut_row + 1 only. build() reads the rows from there and refuses a description that disagrees.
+// last_lu_row.  The lookup SELECTOR columns do (gates/selectors.rs:50-103): table t's end selector is 1 at last_lut_row[t] only; LastLdc is 1
+// at every table's last_lu_row and InitSre at every first_lut_row + 1, and a table's rows lie between the previous table's and the next
+// one's.  build() reads the rows from there and refuses a description that disagrees.
 static int lookup_rows_from_selectors(gl_circuit_desc& d, const uint64_t* h_constants) {
-    if (!d.lut_len) return GL_OK;
+    if (!d.num_luts) return GL_OK;
+    { const char* why = glhost::lookup_shape_error(d); GL_REQUIRE(!why, GL_ERR_UNSUPPORTED, why); }
+    GL_REQUIRE(d.num_constants >= d.num_selectors + d.num_lookup_selectors, GL_ERR_ARG, "bad gate / selector description");
     const size_t n = size_t(1) << d.degree_bits;
-    auto only_one = [&](unsigned sel, uint32_t& row) {
+    auto ones = [&](unsigned sel, std::vector<uint32_t>& rows) {            // the rows where a 0/1 selector column is 1, ascending
         const uint64_t* col = h_constants + (size_t)(d.num_selectors + sel) * n;
-        size_t hits = 0;
-        for (size_t r = 0; r < n; r++) if (col[r] == 1) { row = (uint32_t)r; hits++; } else if (col[r] != 0) return false;
-        return hits == 1;
+        for (size_t r = 0; r < n; r++) if (col[r] == 1) rows.push_back((uint32_t)r); else if (col[r] != 0) return false;
+        return true;
     };
-    uint32_t lu = 0, lut = 0, init = 0;
-    GL_REQUIRE(d.num_lookup_selectors == glhost::LU_SEL_START_END + 1 && d.num_constants >= d.num_selectors + d.num_lookup_selectors && only_one(glhost::LU_SEL_LAST_LDC, lu) &&
-               only_one(glhost::LU_SEL_START_END, lut) && only_one(glhost::LU_SEL_INIT_SRE, init) && init >= 1, GL_ERR_ARG,
-               "lookup selector columns do not describe one table");
-    // a description read from common-data bytes has last_lu_row = 0 (unknown); any row it does name has to agree
-    GL_REQUIRE((!d.last_lu_row || d.last_lu_row == lu) && (!d.last_lut_row || d.last_lut_row == lut) && (!d.first_lut_row || d.first_lut_row == init - 1),
-               GL_ERR_ARG, "the description's lookup rows disagree with the lookup selector columns");
-    d.last_lu_row = lu; d.last_lut_row = lut; d.first_lut_row = init - 1;
+    std::vector<uint32_t> last_ldc, init_sre;
+    GL_REQUIRE(ones(glhost::LU_SEL_LAST_LDC, last_ldc) && ones(glhost::LU_SEL_INIT_SRE, init_sre) && last_ldc.size() == d.num_luts && init_sre.size() == d.num_luts,
+               GL_ERR_ARG, "lookup selector columns do not describe num_luts tables");
+    for (unsigned t = 0; t < d.num_luts; t++) {
+        std::vector<uint32_t> end;
+        GL_REQUIRE(ones(glhost::LU_SEL_START_END + t, end) && end.size() == 1, GL_ERR_ARG, "a table's end selector must be 1 on exactly one row");
+        // tables are placed in order (gadgets/lookup.rs:79-125): the t-th LastLdc / InitSre rows are table t's
+        const uint32_t lu = last_ldc[t], lut = end[0], first = init_sre[t] - 1;
+        GL_REQUIRE(init_sre[t] >= 1 && lu < lut && lut <= first, GL_ERR_ARG, "lookup selector columns do not describe the tables in order");
+        // a description read from common-data bytes has last_lu_row = 0 (unknown); any row it does name has to agree
+        GL_REQUIRE((!d.last_lu_row[t] || d.last_lu_row[t] == lu) && (!d.last_lut_row[t] || d.last_lut_row[t] == lut) && (!d.first_lut_row[t] || d.first_lut_row[t] == first),
+                   GL_ERR_ARG, "the description's lookup rows disagree with the lookup selector columns");
+        d.last_lu_row[t] = lu; d.last_lut_row[t] = lut; d.first_lut_row[t] = first;
+    }
     return GL_OK;
 }
 
@@ -400,15 +406,21 @@ static int lookup_polys_values(gl_ctx* ctx, const gl_circuit* cir, const gl_t* d
     const gl_circuit_desc& d = cir->desc;
     const size_t n = cir->n;
     hipStream_t st = ctx->stream;
-    const uint32_t nrows = d.first_lut_row - d.last_lu_row + 1;
-    DevBuf d_inv(ctx); GL_TRY(d_inv.alloc((size_t)2 * nrows * 64 * sizeof(gl_t)));
+    uint32_t max_rows = 0;
+    for (unsigned t = 0; t < d.num_luts; t++) max_rows = std::max(max_rows, d.first_lut_row[t] - d.last_lu_row[t] + 1);
+    DevBuf d_inv(ctx); GL_TRY(d_inv.alloc((size_t)2 * max_rows * 64 * sizeof(gl_t)));
     gl_t dl[8]; for (int i = 0; i < 8; i++) dl[i] = gl_canon(deltas8[i]);
     ctx->timing_begin("compute lookup polys");
     GL_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)2 * d.num_lookup_polys * n * sizeof(gl_t), st));
-    hipLaunchKernelGGL(k_lookup_inverses, dim3(nrows, 2), dim3(64), 0, st, d_wires, (uint32_t)n, d.last_lu_row, d.last_lut_row,
-                       dl[glhost::LU_CH_A], dl[glhost::LU_CH_ALPHA], dl[4 + glhost::LU_CH_A], dl[4 + glhost::LU_CH_ALPHA], d_inv.as<gl_t>());
-    hipLaunchKernelGGL(k_lookup_scan, dim3(1), dim3(64), 0, st, d_wires, (uint32_t)n, d.last_lu_row, d.last_lut_row, d.first_lut_row,
-                       dl[glhost::LU_CH_B], dl[glhost::LU_CH_DELTA], dl[4 + glhost::LU_CH_B], dl[4 + glhost::LU_CH_DELTA], d_inv.as<const gl_t>(), d_out);
+    // the tables share the polynomials and own disjoint row ranges, each starting from zero on the row above its first table row
+    // (prover.rs:449-454: one pass per LookupWire); the launches of one table follow the previous table's on the stream
+    for (unsigned t = 0; t < d.num_luts; t++) {
+        const uint32_t nrows = d.first_lut_row[t] - d.last_lu_row[t] + 1;
+        hipLaunchKernelGGL(k_lookup_inverses, dim3(nrows, 2), dim3(64), 0, st, d_wires, (uint32_t)n, d.last_lu_row[t], d.last_lut_row[t],
+                           dl[glhost::LU_CH_A], dl[glhost::LU_CH_ALPHA], dl[4 + glhost::LU_CH_A], dl[4 + glhost::LU_CH_ALPHA], d_inv.as<gl_t>());
+        hipLaunchKernelGGL(k_lookup_scan, dim3(1), dim3(64), 0, st, d_wires, (uint32_t)n, d.last_lu_row[t], d.last_lut_row[t], d.first_lut_row[t],
+                           dl[glhost::LU_CH_B], dl[glhost::LU_CH_DELTA], dl[4 + glhost::LU_CH_B], dl[4 + glhost::LU_CH_DELTA], d_inv.as<const gl_t>(), d_out);
+    }
     ctx->timing_end();
     GL_CHECK_HIP(hipGetLastError());
     return GL_OK;
@@ -472,17 +484,14 @@ static int quotient_chunks(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* w
     q.n_field = (gl_t)n; q.lgN = lgN; q.num_constants = d.num_constants; q.num_selectors = d.num_selectors; q.num_gates = d.num_gates;
     q.next_step = 1u << d.rate_bits;
     q.num_lookup_selectors = d.num_lookup_selectors; q.num_lookup_polys = d.num_lookup_polys;
-    q.gate_term0 = 2 + 2 * GLP_CHUNKS + (d.num_lookup_polys ? 2 * GLQ_LOOKUP_TERMS : 0);
+    q.num_luts = d.num_luts;
+    q.gate_term0 = 2 + 2 * GLP_CHUNKS + (d.num_lookup_polys ? 2 * GLQ_LOOKUP_TERMS(d.num_luts) : 0);
     if (d.num_lookup_polys) {
         GL_REQUIRE(deltas8, GL_ERR_ARG, "a circuit with lookups needs the delta challenges");
         for (int i = 0; i < 8; i++) q.deltas[i] = gl_canon(deltas8[i]);
-        for (int c = 0; c < 2; c++) {       // get_lut_poly(..).eval(delta) (vanishing_poly.rs:31-49): combos padded to whole table rows, reversed
-            const size_t deg = (d.lut_len + glhost::LOOKUP_TABLE_SLOTS - 1) / glhost::LOOKUP_TABLE_SLOTS * glhost::LOOKUP_TABLE_SLOTS;
-            gl_t f = 0;
-            for (size_t k = 0; k < deg; k++)
-                f = gl_add(gl_mul(f, q.deltas[4 * c + glhost::LU_CH_DELTA]), k < d.lut_len ? gl_add((gl_t)d.lut[2 * k], gl_mul(q.deltas[4 * c + glhost::LU_CH_B], (gl_t)d.lut[2 * k + 1])) : (gl_t)0);
-            q.lut_poly_at_delta[c] = gl_canon(f);
-        }
+        for (int c = 0; c < 2; c++)
+            for (unsigned t = 0; t < d.num_luts; t++)
+                q.lut_poly_at_delta[c][t] = glhost::lut_poly_at_delta(d, t, q.deltas[4 * c + glhost::LU_CH_B], q.deltas[4 * c + glhost::LU_CH_DELTA]);
     }
     for (unsigned g = 0; g < d.num_gates; g++) { q.gate_types[g] = d.gate_types[g]; q.gate_sel[g] = d.gate_selector_index[g]; q.group_start[g] = d.gate_group_start[g]; q.group_end[g] = d.gate_group_end[g]; }
     ctx->timing_begin("compute quotient polys");

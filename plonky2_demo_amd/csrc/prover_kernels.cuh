@@ -167,16 +167,18 @@ struct GlQuotParams {
     const gl_t* l0_coset;           // L_0 on the coset: l0_coset[i] = Z_H(x_i) / (n (x_i - 1)), x_i = 7 w_N^i (built with the circuit)
     uint32_t lgN, num_constants, num_selectors, num_gates, next_step;
     uint32_t k_is_powers_of_7;
-    uint8_t gate_types[8];
-    uint32_t gate_sel[8], group_start[8], group_end[8];
+    uint8_t gate_types[GL_MAX_GATES];
+    uint32_t gate_sel[GL_MAX_GATES], group_start[GL_MAX_GATES], group_end[GL_MAX_GATES];
     // lookup argument (zero without lookups): the lookup selector columns sit between the gate selectors and the gates' constants, the
-    // lookup polynomials behind Z and the partial products, their 2 x 17 terms between the partial-product checks and the gate terms
-    uint32_t num_lookup_selectors, num_lookup_polys, gate_term0;
+    // lookup polynomials behind Z and the partial products, their 2 x (16 + num_luts) terms between the partial-product checks and the
+    // gate terms
+    uint32_t num_lookup_selectors, num_lookup_polys, num_luts, gate_term0;
     gl_t deltas[8];                 // per challenge: ChallengeA, ChallengeB, ChallengeAlpha, ChallengeDelta (circuit_builder.rs:61-71)
-    gl_t lut_poly_at_delta[2];      // get_lut_poly(..).eval(delta) per challenge (vanishing_poly.rs:31-49), computed on the host
+    gl_t lut_poly_at_delta[2][GL_MAX_LUTS];      // get_lut_poly(table).eval(delta) per challenge (vanishing_poly.rs:31-49), computed on the host
 };
 #define GLQ_MAX_TERMS 192
-#define GLQ_LOOKUP_TERMS 17         // per challenge: last LDC, initial Sum, initial RE, final RE (one table), RE transition, 6 x (Sum, LDC) transitions
+// per challenge: last LDC, initial Sum, initial RE, final RE (one per table), RE transition, 6 x (Sum, LDC) transitions
+#define GLQ_LOOKUP_TERMS(num_luts) (16u + (num_luts))
 
 // running alpha-weighted sums for the two alphas: unreduced (GlxWideAcc2: 16 instructions per term for both), one reduction
 // when the sum is used
@@ -408,27 +410,28 @@ __global__ __launch_bounds__(256) void k_quotient_lookup(GlQuotParams p) {
     const size_t N = size_t(1) << p.lgN;
     if (i >= N) return;
     const gl_t* w = p.wires + i;
-    const gl_t* sel = p.cs + i + (size_t)p.num_selectors * N;       // lookup selectors: TransSre, TransLdc, InitSre, LastLdc, end of the table
+    const gl_t* sel = p.cs + i + (size_t)p.num_selectors * N;       // lookup selectors: TransSre, TransLdc, InitSre, LastLdc, one end per table
     const uint32_t i_next = (i + p.next_step) & (uint32_t)(N - 1);
     const uint32_t NLP = p.num_lookup_polys, num_sldc = NLP - 1;    // 7 and 6
-    const gl_t s_trans_sre = sel[0], s_trans_ldc = sel[N], s_init = sel[2 * N], s_last = sel[3 * N], s_end = sel[4 * N];
+    const gl_t s_trans_sre = sel[0], s_trans_ldc = sel[N], s_init = sel[2 * N], s_last = sel[3 * N];
     gl_t tot[2];
     for (int c = 0; c < 2; c++) {
         const gl_t* ap = p.alpha_pows + (size_t)c * GLQ_MAX_TERMS;
         const gl_t ca = p.deltas[4 * c], cb = p.deltas[4 * c + 1], calpha = p.deltas[4 * c + 2], cdelta = p.deltas[4 * c + 3];
         gl_t acc = 0;
         for (int ch = 0; ch < 2; ch++) {
-            // terms of challenge `ch` weighted by THIS output's alpha: t = 22 + 17 ch + k
+            // terms of challenge `ch` weighted by THIS output's alpha: t = 22 + (16 + num_luts) ch + k
             const gl_t da = p.deltas[4 * ch], db = p.deltas[4 * ch + 1], dalpha = p.deltas[4 * ch + 2], ddelta = p.deltas[4 * ch + 3];
             const gl_t* lz = p.zs + i + (size_t)(2 * GLP_CHUNKS + ch * NLP) * N;
             const gl_t* lzn = p.zs + i_next + (size_t)(2 * GLP_CHUNKS + ch * NLP) * N;
             const gl_t z_re = lz[0], next_z_re = lzn[0];
-            uint32_t t = 2 + 2 * GLP_CHUNKS + GLQ_LOOKUP_TERMS * ch;
+            uint32_t t = 2 + 2 * GLP_CHUNKS + GLQ_LOOKUP_TERMS(p.num_luts) * ch;
             auto term = [&](gl_t v) { acc = gl_add(acc, gl_mul(v, ap[t])); t++; };
             term(gl_mul(s_last, lz[(size_t)num_sldc * N]));                       // last LDC: z_x_sldc[num_sldc - 1]
             term(gl_mul(s_init, lz[N]));                                          // initial Sum: z_x_sldc[0]
             term(gl_mul(s_init, z_re));                                           // initial RE
-            term(gl_mul(s_end, gl_sub(z_re, p.lut_poly_at_delta[ch])));           // final RE
+            for (uint32_t tb = 0; tb < p.num_luts; tb++)                          // final RE: one per table, on the table's end selector
+                term(gl_mul(sel[(size_t)(4 + tb) * N], gl_sub(z_re, p.lut_poly_at_delta[ch][tb])));
             gl_t cur = next_z_re;                                                 // RE transition
 #pragma unroll 1
             for (int sl = 0; sl < 26; sl++) cur = gl_add(gl_mul(cur, ddelta), gl_add(w[(size_t)(3 * sl) * N], gl_mul(db, w[(size_t)(3 * sl + 1) * N])));

@@ -11,6 +11,8 @@
 // Only circuits this library can prove / verify are representable: the five gates of the demo + BaseSumGate<2>, standard_recursion_config's
 // shape (no lookups, no zero-knowledge); anything else is GL_ERR_UNSUPPORTED when reading.
 #include "context.hpp"
+#include "host_circuit.hpp"
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -29,7 +31,10 @@ struct Writer {
     void u64(uint64_t x) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(x >> (8 * i))); }       // write_usize (mod.rs:1220-1222)
     void field(gl_t x) { u64(gl_canon(x)); }                                                          // write_field (mod.rs:1237-1242)
     void u16(uint16_t x) { b.push_back((uint8_t)x); b.push_back((uint8_t)(x >> 8)); }
-    void lut(const gl_circuit_desc& d) { u64(d.lut_len); for (uint32_t i = 0; i < 2 * d.lut_len; i++) u16(d.lut[i]); }      // write_lut (mod.rs:2077-2085)
+    void lut(const gl_circuit_desc& d, unsigned t) {                                                 // write_lut (mod.rs:2077-2085)
+        const uint16_t* e = d.lut + 2 * (size_t)glhost::lut_offset(d, t);
+        u64(d.lut_len[t]); for (uint32_t i = 0; i < 2 * d.lut_len[t]; i++) u16(e[i]);
+    }
 };
 struct Reader {
     const uint8_t* p; size_t n, pos = 0; bool ok = true;
@@ -73,12 +78,13 @@ int read_fri_config(Reader& r, gl_circuit_desc& d) {
 extern "C" int gl_common_data_to_bytes(const gl_circuit_desc* desc, uint8_t* h_out, size_t cap, size_t* num_bytes) {
     GL_REQUIRE(desc && num_bytes, GL_ERR_ARG, "gl_common_data_to_bytes: null argument");
     const gl_circuit_desc& d = *desc;
-    GL_REQUIRE(d.num_gates >= 1 && d.num_gates <= 8 && d.num_fri_rounds <= 8 && d.num_selectors >= 1 && d.num_selectors <= 4, GL_ERR_ARG, "bad circuit description");
+    GL_REQUIRE(d.num_gates >= 1 && d.num_gates <= GL_MAX_GATES && d.num_fri_rounds <= 8 && d.num_selectors >= 1 && d.num_selectors <= 4, GL_ERR_ARG, "bad circuit description");
     // everything the writer indexes or divides by (k_is holds 80 entries)
     GL_REQUIRE(d.num_routed_wires >= 4 && d.num_routed_wires <= 80 && d.quotient_degree_factor >= 1 && d.num_constants >= d.num_selectors, GL_ERR_ARG,
                "bad circuit description: routed wires 4..80, quotient degree factor >= 1, constants >= selectors");
     for (uint32_t g = 0; g < d.num_gates; g++) GL_REQUIRE(d.gate_types[g] <= 7, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable}");
-    GL_REQUIRE(d.lut_len <= GL_MAX_LUT_ENTRIES && d.num_constants >= d.num_selectors + d.num_lookup_selectors, GL_ERR_ARG, "bad lookup description");
+    { const char* why = glhost::lookup_shape_error(d); GL_REQUIRE(!why, GL_ERR_ARG, why); }
+    GL_REQUIRE(d.num_constants >= d.num_selectors + d.num_lookup_selectors, GL_ERR_ARG, "bad lookup description");
     Writer w;
     // CircuitConfig (mod.rs:1662-1686)
     w.u64(d.num_wires); w.u64(d.num_routed_wires); w.u64(STD_CONFIG_NUM_CONSTANTS); w.u64(STD_SECURITY_BITS); w.u64(d.num_challenges);
@@ -95,8 +101,8 @@ extern "C" int gl_common_data_to_bytes(const gl_circuit_desc* desc, uint8_t* h_o
         w.u32(gate_tag(d.gate_types[g]));
         if (d.gate_types[g] == 3) w.u64(d.num_routed_wires / 4);                   // ArithmeticGate { num_ops }
         if (d.gate_types[g] == 1) w.u64(d.num_constants - d.num_selectors - d.num_lookup_selectors);      // ConstantGate { num_consts }
-        if (d.gate_types[g] == 6) { w.u64(LOOKUP_SLOTS); w.lut(d); }                // LookupGate { num_slots, lut } (gates/lookup.rs:59-62)
-        if (d.gate_types[g] == 7) { w.u64(LOOKUP_TABLE_SLOTS); w.lut(d); w.u64(d.last_lut_row); }      // LookupTableGate (gates/lookup_table.rs:70-74)
+        if (d.gate_types[g] == 6) { w.u64(LOOKUP_SLOTS); w.lut(d, d.gate_luts[g]); }                // LookupGate { num_slots, lut } (gates/lookup.rs:59-62)
+        if (d.gate_types[g] == 7) { w.u64(LOOKUP_TABLE_SLOTS); w.lut(d, d.gate_luts[g]); w.u64(d.last_lut_row[d.gate_luts[g]]); }      // LookupTableGate (gates/lookup_table.rs:70-74)
         if (d.gate_types[g] == 5) w.u64(BASE_SUM_LIMBS);                           // BaseSumGate<2> { num_limbs } (gates/base_sum.rs:53-55)
         const uint64_t c = gate_constraints(d.gate_types[g], d);
         if (c > max_constraints) max_constraints = c;
@@ -113,7 +119,7 @@ extern "C" int gl_common_data_to_bytes(const gl_circuit_desc* desc, uint8_t* h_o
     w.u64(d.num_routed_wires); for (uint32_t j = 0; j < d.num_routed_wires; j++) w.field(d.k_is[j]);
     w.u64((d.num_routed_wires + d.quotient_degree_factor - 1) / d.quotient_degree_factor - 1);      // num_partial_products (circuit_builder.rs, util/partial_products.rs:40-47)
     w.u64(d.num_lookup_polys); w.u64(d.num_lookup_selectors);                      // mod.rs:1776-1782
-    w.u64(d.lut_len ? 1 : 0); if (d.lut_len) w.lut(d);                             // luts: at most the one table
+    w.u64(d.num_luts); for (unsigned t = 0; t < d.num_luts; t++) w.lut(d, t);      // luts
     *num_bytes = w.b.size();
     if (!h_out) return GL_OK;
     GL_REQUIRE(cap >= w.b.size(), GL_ERR_ARG, "gl_common_data_to_bytes: output too small");
@@ -150,10 +156,12 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
     GL_REQUIRE(fp.rate_bits == d.rate_bits && fp.cap_height == d.cap_height && fp.num_query_rounds == d.num_query_rounds && fp.proof_of_work_bits == d.proof_of_work_bits,
                GL_ERR_ARG, "fri_params.config differs from config.fri_config");
     const uint64_t ngates = r.u64();
-    GL_REQUIRE(r.ok && ngates >= 1 && ngates <= 8, GL_ERR_UNSUPPORTED, "1..8 gate types");
+    GL_REQUIRE(r.ok && ngates >= 1 && ngates <= GL_MAX_GATES, GL_ERR_UNSUPPORTED, "1..16 gate types");
     d.num_gates = (uint32_t)ngates;
-    uint64_t arith_ops = 0, const_consts = 0, gate_lut_len = 0;
-    bool lut_differs = false;
+    uint64_t arith_ops = 0, const_consts = 0;
+    // a lookup gate carries its whole table (lookup.rs:59-62, lookup_table.rs:70-74); which entry of `luts` it is gets settled below
+    std::vector<uint16_t> gate_table[GL_MAX_GATES];
+    uint32_t gate_last_lut_row[GL_MAX_GATES] = {0};
     for (uint64_t g = 0; g < ngates; g++) {
         const uint32_t tag = r.u32();
         if (tag == TAG_NOOP) d.gate_types[g] = 0;
@@ -171,10 +179,8 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
             const uint64_t slots = r.u64(), len = r.u64();
             GL_REQUIRE(!r.ok || (slots == (tag == TAG_LOOKUP ? LOOKUP_SLOTS : LOOKUP_TABLE_SLOTS) && len >= 1 && len <= GL_MAX_LUT_ENTRIES), GL_ERR_UNSUPPORTED,
                        "lookup gate: slot count of standard_recursion_config and a table of at most 1024 entries");
-            GL_REQUIRE(!r.ok || !gate_lut_len || gate_lut_len == len, GL_ERR_UNSUPPORTED, "more than one lookup table");
-            for (uint64_t k = 0; k < 2 * len && r.ok; k++) { const uint16_t v = r.u16(); if (gate_lut_len && d.lut[k] != v) lut_differs = true; d.lut[k] = v; }
-            gate_lut_len = len;
-            if (tag == TAG_LOOKUP_TABLE) d.last_lut_row = r.usize32();
+            for (uint64_t k = 0; k < 2 * len && r.ok; k++) gate_table[g].push_back(r.u16());
+            if (tag == TAG_LOOKUP_TABLE) gate_last_lut_row[g] = r.usize32();
         }
         else return gl_fail(GL_ERR_UNSUPPORTED, "gate outside {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable}", __FILE__, __LINE__);
     }
@@ -200,19 +206,38 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
     const uint64_t nlp = r.u64(), nls = r.u64(), nluts = r.u64();
     GL_REQUIRE(!r.wide, GL_ERR_UNSUPPORTED, "a size field of CommonCircuitData exceeds 32 bits");
     GL_REQUIRE(r.ok, GL_ERR_ARG, "truncated CommonCircuitData");
-    GL_REQUIRE(nluts <= 1 && ((nluts == 0 && nlp == 0 && nls == 0 && !gate_lut_len) || (nluts == 1 && nlp == 7 && nls == 5 && gate_lut_len)), GL_ERR_UNSUPPORTED,
-               "lookup argument: one table, 7 lookup polynomials and 5 lookup selectors per challenge");
-    if (nluts) {
+    GL_REQUIRE(nluts <= GL_MAX_LUTS && ((nluts == 0 && nlp == 0 && nls == 0) || (nluts >= 1 && nlp == 7 && nls == glhost::LU_SEL_START_END + nluts)), GL_ERR_UNSUPPORTED,
+               "lookup argument: at most 4 tables, 7 lookup polynomials and 4 + #tables lookup selectors per challenge");
+    d.num_luts = (uint32_t)nluts; d.num_lookup_polys = (uint32_t)nlp; d.num_lookup_selectors = (uint32_t)nls;
+    uint32_t total = 0;
+    for (uint64_t t = 0; t < nluts; t++) {
         const uint64_t len = r.u64();
-        GL_REQUIRE(r.ok && len == gate_lut_len, GL_ERR_ARG, "the lookup table of CommonCircuitData differs from the lookup gates'");
-        for (uint64_t k = 0; k < 2 * len && r.ok; k++) if (r.u16() != d.lut[k]) lut_differs = true;
-        GL_REQUIRE(r.ok, GL_ERR_ARG, "truncated CommonCircuitData");
-        GL_REQUIRE(!lut_differs, GL_ERR_ARG, "the lookup table of CommonCircuitData differs from the lookup gates'");
-        d.lut_len = (uint32_t)len; d.num_lookup_polys = (uint32_t)nlp; d.num_lookup_selectors = (uint32_t)nls;
-        // LookupWire is prover data (circuit_data.rs:296-299), not part of these bytes: last_lu_row / first_lut_row are derived from the
-        // LookupTableGate's last_lut_row and the table length; last_lu_row is unknown here and left 0 (the verifier does not need it)
-        d.first_lut_row = d.last_lut_row + (uint32_t)((len + LOOKUP_TABLE_SLOTS - 1) / LOOKUP_TABLE_SLOTS) - 1;
+        GL_REQUIRE(r.ok && len >= 1 && total + len <= GL_MAX_LUT_ENTRIES, GL_ERR_UNSUPPORTED, "lookup tables: 1 .. 1024 entries together");
+        d.lut_len[t] = (uint32_t)len;
+        for (uint64_t k = 0; k < 2 * len && r.ok; k++) d.lut[2 * (size_t)total + k] = r.u16();
+        total += (uint32_t)len;
     }
+    GL_REQUIRE(r.ok, GL_ERR_ARG, "truncated CommonCircuitData");
+    bool has_table_gate[GL_MAX_LUTS] = {false};
+    for (uint64_t g = 0; g < ngates; g++) {
+        if (d.gate_types[g] != 6 && d.gate_types[g] != 7) continue;
+        unsigned t = 0;                 // the tables of `luts` are distinct (circuit_builder.rs is_stored): the first equal one is the gate's
+        for (; t < nluts; t++) {
+            const uint16_t* e = d.lut + 2 * (size_t)glhost::lut_offset(d, t);
+            if (gate_table[g].size() == 2 * (size_t)d.lut_len[t] && std::equal(gate_table[g].begin(), gate_table[g].end(), e)) break;
+        }
+        GL_REQUIRE(t < nluts, GL_ERR_ARG, "a lookup gate's table is not one of CommonCircuitData's luts");
+        d.gate_luts[g] = (uint8_t)t;
+        if (d.gate_types[g] == 7) {
+            // LookupWire is prover data (circuit_data.rs:296-299), not part of these bytes: last_lut_row is the LookupTableGate's field,
+            // first_lut_row follows from the table length; last_lu_row is unknown here and left 0 (the verifier does not need it; build()
+            // reads it from the lookup selector columns)
+            d.last_lut_row[t] = gate_last_lut_row[g];
+            d.first_lut_row[t] = gate_last_lut_row[g] + glhost::lut_rows(d, t) - 1;
+            has_table_gate[t] = true;
+        }
+    }
+    for (uint64_t t = 0; t < nluts; t++) GL_REQUIRE(has_table_gate[t], GL_ERR_ARG, "a lookup table without its LookupTableGate");
     GL_REQUIRE(max_qdf == d.quotient_degree_factor && cfg_consts + d.num_selectors + d.num_lookup_selectors == d.num_constants, GL_ERR_UNSUPPORTED, "constants / quotient degree layout");
     GL_REQUIRE((!arith_ops || arith_ops == d.num_routed_wires / 4) && (!const_consts || const_consts == cfg_consts), GL_ERR_UNSUPPORTED, "gate parameters");
     *out = d;

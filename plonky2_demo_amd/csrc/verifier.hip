@@ -144,10 +144,9 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
     const gl_circuit_desc& d = *desc;
     GL_REQUIRE(d.num_wires == 135 && d.num_routed_wires == 80 && d.num_challenges == 2 && d.quotient_degree_factor == 8 && d.rate_bits == 3,
                GL_ERR_UNSUPPORTED, "gl_verify: only standard_recursion_config circuits are supported");
-    GL_REQUIRE((d.num_lookup_polys == 0 && d.num_lookup_selectors == 0 && d.lut_len == 0) ||
-               (d.num_lookup_polys == 7 && d.num_lookup_selectors == 5 && d.lut_len >= 1 && d.lut_len <= GL_MAX_LUT_ENTRIES), GL_ERR_UNSUPPORTED,
-               "gl_verify: lookups: one table of at most 1024 entries, 7 lookup polynomials and 5 lookup selectors per challenge");
-    GL_REQUIRE(d.num_gates >= 1 && d.num_gates <= 8 && d.num_selectors >= 1 && d.num_constants == d.num_selectors + d.num_lookup_selectors + 2 && d.num_fri_rounds <= 8 &&
+    GL_REQUIRE(d.num_gates >= 1 && d.num_gates <= GL_MAX_GATES, GL_ERR_ARG, "gl_verify: bad gate count");
+    { const char* why = glhost::lookup_shape_error(d); GL_REQUIRE(!why, GL_ERR_UNSUPPORTED, why); }
+    GL_REQUIRE(d.num_selectors >= 1 && d.num_constants == d.num_selectors + d.num_lookup_selectors + 2 && d.num_fri_rounds <= 8 &&
                d.degree_bits >= 1 && d.degree_bits + d.rate_bits <= 32 && d.cap_height <= d.degree_bits + d.rate_bits && d.num_query_rounds >= 1,
                GL_ERR_ARG, "gl_verify: bad circuit description");
     for (unsigned g = 0; g < d.num_gates; g++)
@@ -308,15 +307,9 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
                 terms.push_back(e_mul(sel[glhost::LU_SEL_LAST_LDC], zx(num_sldc - 1)));
                 terms.push_back(e_mul(sel[glhost::LU_SEL_INIT_SRE], zx(0)));
                 terms.push_back(e_mul(sel[glhost::LU_SEL_INIT_SRE], z_re));
-                {   // final RE: the table's polynomial at delta (get_lut_poly, vanishing_poly.rs:31-49): combos zero-padded to whole rows, reversed
-                    const size_t rows = (d.lut_len + glhost::LOOKUP_TABLE_SLOTS - 1) / glhost::LOOKUP_TABLE_SLOTS, deg = rows * glhost::LOOKUP_TABLE_SLOTS;
-                    gl_t f = 0;
-                    for (size_t k = 0; k < deg; k++) {
-                        const gl_t c = k < d.lut_len ? gl_add((gl_t)d.lut[2 * k], gl_mul(dl[glhost::LU_CH_B], (gl_t)d.lut[2 * k + 1])) : 0;
-                        f = gl_add(gl_mul(f, dl[glhost::LU_CH_DELTA]), c);
-                    }
-                    terms.push_back(e_mul(sel[glhost::LU_SEL_START_END], e_sub(z_re, e_of(gl_canon(f)))));
-                }
+                // final RE, one per table: the table's polynomial at delta (get_lut_poly, vanishing_poly.rs:31-49), on the table's end selector
+                for (unsigned t = 0; t < d.num_luts; t++)
+                    terms.push_back(e_mul(sel[glhost::LU_SEL_START_END + t], e_sub(z_re, e_of(glhost::lut_poly_at_delta(d, t, dl[glhost::LU_CH_B], dl[glhost::LU_CH_DELTA])))));
                 E cur = next_z_re;
                 for (int sl = 0; sl < glhost::LOOKUP_TABLE_SLOTS; sl++) cur = e_add(e_scale(cur, dl[glhost::LU_CH_DELTA]), combo[sl]);
                 terms.push_back(e_mul(sel[glhost::LU_SEL_TRANS_SRE], e_sub(z_re, cur)));

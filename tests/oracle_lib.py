@@ -294,7 +294,7 @@ class OracleCircuit:
         d.num_public_inputs = i["num_public_inputs"]
         order = self.gate_order()
         d.num_gates = len(order)
-        groups = np.zeros(3 * 8, dtype=np.uint64)
+        groups = np.zeros(3 * 16, dtype=np.uint64)
         lib.orc_circuit_selector_groups(self.h, _p(groups))
         for g, t in enumerate(order):
             d.gate_types[g] = t
@@ -303,12 +303,17 @@ class OracleCircuit:
         lib.orc_circuit_k_is(self.h, _p(k))
         for j in range(80):
             d.k_is[j] = int(k[j])
-        li = np.zeros(6, dtype=np.uint64)
-        lut = np.zeros(2048, dtype=np.uint16)
-        lib.orc_circuit_lookup_info(self.h, _p(li), lut.ctypes.data_as(ctypes.c_void_p))
-        d.num_lookup_polys, d.num_lookup_selectors, d.last_lu_row, d.last_lut_row, d.first_lut_row, d.lut_len = [int(x) for x in li]
-        for j in range(2 * d.lut_len):
+        li, rows = np.zeros(3, dtype=np.uint64), np.zeros(4 * 8, dtype=np.uint64)
+        lut, gate_luts = np.zeros(2048, dtype=np.uint16), np.zeros(16, dtype=np.uint8)
+        lib.orc_circuit_lookup_info(self.h, _p(li), _p(rows), lut.ctypes.data_as(ctypes.c_void_p), gate_luts.ctypes.data_as(ctypes.c_void_p))
+        d.num_lookup_polys, d.num_lookup_selectors, d.num_luts = [int(x) for x in li]
+        assert d.num_luts <= 4
+        for t in range(d.num_luts):
+            d.last_lu_row[t], d.last_lut_row[t], d.first_lut_row[t], d.lut_len[t] = [int(x) for x in rows[4 * t:4 * t + 4]]
+        for j in range(2 * sum(d.lut_len[t] for t in range(d.num_luts))):
             d.lut[j] = int(lut[j])
+        for g in range(d.num_gates):
+            d.gate_luts[g] = int(gate_luts[g])
         return d
 
     @property
@@ -334,7 +339,7 @@ class OracleCircuit:
         return out
 
     def gate_order(self):
-        out = np.empty(8, dtype=np.uint8)
+        out = np.empty(32, dtype=np.uint8)
         k = self.o.lib.orc_circuit_gate_order(self.h, _p(out))
         return out[:k].tolist()
 

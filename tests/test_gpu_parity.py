@@ -888,17 +888,23 @@ def test_range_check_circuits_with_base_sum_gate(gpu, orc, bits, value):
     (8, 40, [7] * 40),                                # one full LookupGate row, one table entry with multiplicity 40
     (8, 81, [(5 * i) % 256 for i in range(81)]),      # three LookupGate rows, n = 64 (one FRI reduction)
     (9, 3, [1000, 1037, 1333]),                       # a 10-entry table whose inputs are not their indices
+    (10, 2, [3, 200, 17, 255]),                       # lookup_test.rs test_two_luts: two 256-entry tables, outputs added by an ArithmeticGate
+    (10, 45, [(7 * i) % 256 for i in range(90)]),     # two tables with two LookupGate rows each
+    (11, 3, [2, 9, 5, 0, 128, 255]),                  # test_different_inputs: an 8-entry table next to a 256-entry one
+    (12, 2, [1, 2, 3, 4]),                            # test_same_luts: the same table added twice is stored once
 ])
 def test_lookup_argument_circuits(gpu, orc, kind, param, inputs):
     # the lookup argument on the GPU (plonk/prover.rs:425-572: lookup polynomials; plonk/vanishing_poly.rs:503-670: their constraints in the
     # quotient; 4 extra challenges; 2 x 7 more columns in the Z batch, opened at zeta and g zeta, last in both FRI batches): proof bytes ==
-    # the oracle's, both verifiers accept, outputs are the table's.  ONE table.  PARITY UNPINNED against a Rust proof.
+    # the oracle's, both verifiers accept, outputs are the tables'.  Up to GL_MAX_LUTS tables: one LookupGate and one LookupTableGate type
+    # per table, one end selector and one final-RE constraint each.  PARITY UNPINNED against a Rust proof.
     p, ctx = gpu
     oc = orc.circuit_of_kind(kind, param, threads=8)
     w = oc.witness(np.array(inputs, dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=5)
     gp = _prove_generic_and_compare(p, oc, w)
-    table = {i: (3 * i * i + 5 * i + 7) % 256 for i in range(256)} if kind == 8 else {1000 + 37 * i: 17 * i * i + 3 for i in range(10)}
-    assert [int(x) for x in w.public_inputs()] == inputs + [table[v] for v in inputs]
+    from test_verifier import lookup_outputs
+    expected, nluts = lookup_outputs(kind, param, inputs)
+    assert [int(x) for x in w.public_inputs()] == expected and oc.product_desc().num_luts == nluts
     # the lookup polynomials themselves: 14 value columns behind Z and the partial products, equal to the oracle's
     zs_g, zs_o = gp.zs_partial_products(34), w.prove(threads=8).zs_partial_products(34)
     assert zs_g.shape[0] == 34 and (zs_g == zs_o).all()
@@ -916,14 +922,24 @@ def test_lookup_rows_come_from_the_selector_columns(gpu, orc):
     w = oc.witness(np.arange(3, 53, dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=9)
     desc = oc.product_desc()
     d2, _ = api.common_data_from_bytes(api.common_data_to_bytes(desc))
-    assert d2.last_lu_row == 0 and desc.last_lu_row != 0 and d2.last_lut_row == desc.last_lut_row
+    assert d2.last_lu_row[0] == 0 and desc.last_lu_row[0] != 0 and d2.last_lut_row[0] == desc.last_lut_row[0]
     cd = p.GenericCircuitData(d2, oc.constants_sigmas())
+    assert bytes(cd.desc) == bytes(desc)              # gl_circuit_description: the rows filled in
     assert cd.prove(w.wires(), w.public_inputs()).to_bytes() == w.prove(threads=8).to_bytes()
     for field in ("last_lu_row", "last_lut_row", "first_lut_row"):
         bad = copy.copy(desc)
-        setattr(bad, field, getattr(desc, field) + 1)
+        getattr(bad, field)[0] += 1
         with pytest.raises(p.Plonky2Mi355xError, match="lookup"):
             p.GenericCircuitData(bad, oc.constants_sigmas())
+    # two tables: the t-th LastLdc / InitSre rows and the t-th end selector are table t's
+    oc2 = orc.circuit_of_kind(11, 3, threads=8)
+    w2 = oc2.witness(np.array([2, 9, 5, 0, 128, 255], dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=9)
+    desc2 = oc2.product_desc()
+    d3, _ = api.common_data_from_bytes(api.common_data_to_bytes(desc2))
+    assert [d3.last_lu_row[t] for t in range(2)] == [0, 0]
+    cd2 = p.GenericCircuitData(d3, oc2.constants_sigmas())
+    assert bytes(cd2.desc) == bytes(desc2)
+    assert cd2.prove(w2.wires(), w2.public_inputs()).to_bytes() == w2.prove(threads=8).to_bytes()
 
 
 def test_phase_api_on_a_lookup_circuit_with_an_external_transcript(gpu, orc):

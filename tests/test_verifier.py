@@ -210,7 +210,7 @@ def test_common_data_writer_validates_its_description():
     import plonky2_demo_amd as p
     from plonky2_demo_amd import api
     hc = p.MatmulCircuit(2)
-    for field, value in (("num_routed_wires", 81), ("num_routed_wires", 2**31), ("quotient_degree_factor", 0), ("num_constants", 1), ("num_gates", 9)):
+    for field, value in (("num_routed_wires", 81), ("num_routed_wires", 2**31), ("quotient_degree_factor", 0), ("num_constants", 1), ("num_gates", 17)):
         d = copy.copy(hc.desc)
         setattr(d, field, value)
         with pytest.raises(p.Plonky2Mi355xError):
@@ -220,8 +220,16 @@ def test_common_data_writer_validates_its_description():
     with pytest.raises(p.Plonky2Mi355xError) as e:
         api.common_data_to_bytes(d)
     assert e.value.code == 3
+    for nluts, lens in ((1, [2000]), (2, [600, 600]), (5, [1] * 4), (1, [0])):       # must not index past lut[2048] / lut_len[4]
+        d = copy.copy(hc.desc)
+        d.num_luts, d.num_lookup_polys, d.num_lookup_selectors = nluts, 7, 4 + nluts
+        for t, n_ in enumerate(lens):
+            d.lut_len[t] = n_
+        with pytest.raises(p.Plonky2Mi355xError):
+            api.common_data_to_bytes(d)
     d = copy.copy(hc.desc)
-    d.lut_len = 2000                                      # beyond GL_MAX_LUT_ENTRIES: must not index past lut[2048]
+    d.gate_luts[0] = 1                                    # a table index on a gate that has none
+    d.num_luts, d.num_lookup_polys, d.num_lookup_selectors, d.lut_len[0] = 1, 7, 5, 4
     with pytest.raises(p.Plonky2Mi355xError):
         api.common_data_to_bytes(d)
 
@@ -265,15 +273,33 @@ def test_base_sum_gate_circuits_verify_natively_and_through_the_byte_form(orc, b
     assert e.value.code == 3
 
 
+def lookup_outputs(kind, param, inputs):
+    """Public inputs the oracle's lookup circuits (oracle/gl_circuit.hpp kinds 8-12) must produce, and their number of tables."""
+    P = 2**64 - 2**32 + 1
+    big = {i: (3 * i * i + 5 * i + 7) % 256 for i in range(256)}
+    if kind == 8:
+        return inputs + [big[v] for v in inputs], 1
+    if kind == 9:
+        t = {1000 + 37 * i: 17 * i * i + 3 for i in range(10)}
+        return inputs + [t[v] for v in inputs], 1
+    first = {10: {i: (7 * i + 1) % 256 for i in range(256)}, 11: {i: i * i + 1 for i in range(2, 10)}, 12: big}[kind]
+    outs = [first[v] for v in inputs[:param]] + [big[v] for v in inputs[param:]]
+    return inputs + outs + ([(outs[0] + outs[param]) % P] if kind == 10 else []), (1 if kind == 12 else 2)
+
+
 @pytest.mark.parametrize("kind,param,inputs", [
     (8, 2, [1, 2]),                                   # lookup_test.rs test_one_lookup: two lookups in a 256-entry table
     (8, 50, list(range(3, 53))),                      # test_many_lookups: two LookupGate rows, the second padded with the table's first entry
     (8, 40, [7] * 40),                                # exactly one full LookupGate row (no padding), one entry looked up 40 times
     (9, 3, [1000, 1037, 1333]),                       # a 10-entry table whose inputs are not their indices
+    (10, 2, [3, 200, 17, 255]),                       # test_two_luts: two 256-entry tables, two lookups each, outputs added
+    (10, 45, [(7 * i) % 256 for i in range(90)]),     # two tables, two LookupGate rows each
+    (11, 3, [2, 9, 5, 0, 128, 255]),                  # test_different_inputs: an 8-entry table on 2..9 next to a 256-entry one
+    (12, 2, [1, 2, 3, 4]),                            # test_same_luts: the same table added twice is ONE table
 ])
 def test_lookup_argument_circuits_verify_natively_and_through_the_byte_form(orc, kind, param, inputs):
-    # the lookup argument (plonk/prover.rs:425-572, plonk/vanishing_poly.rs:337-670; LookupGate / LookupTableGate, gate types 6 / 7, ONE
-    # table): the oracle proves (its quotient exists: every lookup constraint vanishes on H), its verifier and the product's independently
+    # the lookup argument (plonk/prover.rs:425-572, plonk/vanishing_poly.rs:337-670; LookupGate / LookupTableGate, gate types 6 / 7, one
+    # of each PER TABLE): the oracle proves (its quotient exists: every lookup constraint vanishes on H), its verifier and the product's independently
     # written gl_verify accept, both give the same verdict on 60 single-bit mutations, the outputs are the table's, and the circuit data
     # (lookup gates with their table, num_lookup_polys / selectors, luts) equals the oracle writer's bytes and round-trips.  PARITY UNPINNED.
     import ctypes
@@ -282,13 +308,16 @@ def test_lookup_argument_circuits_verify_natively_and_through_the_byte_form(orc,
     oc = orc.circuit_of_kind(kind, param, threads=4)
     w = oc.witness(np.array(inputs, dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=2)
     pis = [int(x) for x in w.public_inputs()]
-    table = {i: (3 * i * i + 5 * i + 7) % 256 for i in range(256)} if kind == 8 else {1000 + 37 * i: 17 * i * i + 3 for i in range(10)}
-    assert pis[:param] == inputs and pis[param:] == [table[v] for v in inputs]
+    expected, nluts = lookup_outputs(kind, param, inputs)
+    assert pis == expected
     pr = w.prove(threads=4)
     assert pr.verify()[0]
     by = pr.to_bytes()
     desc = oc.product_desc()
-    assert desc.num_lookup_polys == 7 and desc.num_lookup_selectors == 5 and {6, 7} <= set(list(desc.gate_types)[:desc.num_gates])
+    assert desc.num_luts == nluts and desc.num_lookup_polys == 7 and desc.num_lookup_selectors == 4 + nluts
+    gates = list(desc.gate_types)[:desc.num_gates]
+    assert gates.count(6) == nluts and gates.count(7) == nluts
+    assert sorted(desc.gate_luts[g] for g in range(desc.num_gates) if gates[g] == 7) == list(range(nluts))
     cap, dig = np.ascontiguousarray(oc.constants_sigmas_cap), np.ascontiguousarray(oc.digest)
     vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
 
@@ -305,7 +334,9 @@ def test_lookup_argument_circuits_verify_natively_and_through_the_byte_form(orc,
     assert common == oc.data_bytes(0)
     d2, used = api.common_data_from_bytes(common)
     assert used == len(common)
-    d2.last_lu_row = desc.last_lu_row                 # LookupWire.last_lu_gate is prover data: not in CommonCircuitData's bytes
+    for t in range(nluts):
+        assert d2.last_lu_row[t] == 0
+        d2.last_lu_row[t] = desc.last_lu_row[t]       # LookupWire.last_lu_gate is prover data: not in CommonCircuitData's bytes
     assert bytes(d2) == bytes(desc)
     vd = api.verifier_data_to_bytes(desc, cap, dig)
     assert vd == oc.data_bytes(1) and api.verify_bytes(vd, by) == (True, "")
