@@ -19,6 +19,7 @@
 // instead of 7 / 10 with two fix-ups, 6-11 for a shift twiddle instead of 8-26; general multiplies three at a time).  The stores
 // need no final canonicalisation.
 #pragma once
+#include <type_traits>
 #include "gl64.cuh"
 #include "gl64_gfx950.cuh"
 
@@ -383,17 +384,25 @@ __device__ __forceinline__ void ntt_col_tile(const NttPassParams& p, gl_t* lds, 
         ntt_fill_lds_twiddles<LOGL>(lds, p.tw_local, tid);
         const uint32_t n_in = p.n_in;
         const gl_t* pre_lo = p.pre_lo; const gl_t* pre_hi = p.pre_hi;
-        ntt_first_stage_direct<LOGL, INV, ZP, true>(lds, tid,
-            [&](int t, int i1) -> gl_t {
-                const uint32_t i = ((uint32_t)i1 << lgN2) + c0 + (uint32_t)t;
-                return (i < n_in) ? ntt_ld(src, i) : (gl_t)0;
-            },
-            [&](int t, int i1, gl_t v) -> gl_t {
-                const uint32_t i = ((uint32_t)i1 << lgN2) + c0 + (uint32_t)t;
-                if (pre_lo && i < n_in) return glx_mul<true>(v, ntt_pow2level(pre_lo, pre_hi, i));
-                return glx_canon(v);                  // the caller's values may be any u64 representatives
-            },
-            [] {});
+        // FULL: every point the tile reads exists (wave-uniform; always so for a transform of n_in = N points): no per-element
+        // range check, i.e. no exec-masked region and no zero fill around each of the thread's 16 loads
+        auto first_stage = [&](auto full) {
+            constexpr bool FULL = decltype(full)::value;
+            ntt_first_stage_direct<LOGL, INV, ZP, true>(lds, tid,
+                [&](int t, int i1) -> gl_t {
+                    const uint32_t i = ((uint32_t)i1 << lgN2) + c0 + (uint32_t)t;
+                    if constexpr (FULL) return ntt_ld(src, i);
+                    else return (i < n_in) ? ntt_ld(src, i) : (gl_t)0;
+                },
+                [&](int t, int i1, gl_t v) -> gl_t {
+                    const uint32_t i = ((uint32_t)i1 << lgN2) + c0 + (uint32_t)t;
+                    if (pre_lo && (FULL || i < n_in)) return glx_mul<true>(v, ntt_pow2level(pre_lo, pre_hi, i));
+                    return glx_canon(v);                  // the caller's values may be any u64 representatives
+                },
+                [] {});
+        };
+        constexpr uint32_t LAST_ROW = ZP ? (G::L / 8 - 1) : (G::L - 1);          // the last row of the tile that is read at all
+        if (((LAST_ROW << lgN2) + c0 + (uint32_t)T - 1) < n_in) first_stage(std::true_type{}); else first_stage(std::false_type{});
         __syncthreads();
         ntt_lds_stages<LOGL, ntt_first_radix(LOGL), INV, ZP>(lds, p.tw_local, tid);
     } else {
