@@ -52,24 +52,26 @@ __device__ __forceinline__ void glx_mul3(gl_t aA, gl_t bA, gl_t aB, gl_t bB, gl_
           [a0C] "v"((u32)aC), [a1C] "v"((u32)(aC >> 32)), [b0C] "v"((u32)bC), [b1C] "v"((u32)(bC >> 32))
         : "vcc");
     // product words: w0 = p00.lo, w1 = p00.hi + mid.lo, w2 = p11.lo + mid.hi + carry, w3 = p11.hi + carry (+ cm, kept apart).
-    // Computed in place (tied operands): (w0, w1) stays the register pair of p00 and feeds the next multiply-add without a move.
-    u32 w1A = (u32)(p00A >> 32), w2A = (u32)p11A, w3A = (u32)(p11A >> 32);
-    u32 w1B = (u32)(p00B >> 32), w2B = (u32)p11B, w3B = (u32)(p11B >> 32);
-    u32 w1C = (u32)(p00C >> 32), w2C = (u32)p11C, w3C = (u32)(p11C >> 32);
+    // w1 is computed in place (tied operand): (w0, w1) stays the register pair of p00 and feeds the next multiply-add without a move.
+    // w2 and w3 are only ever used as single words, so they are FRESH outputs: tying both halves of p11's pair costs one register copy
+    // per product (the allocator splits the pair and rejoins only one half).
+    u32 w1A = (u32)(p00A >> 32), w1B = (u32)(p00B >> 32), w1C = (u32)(p00C >> 32), w2A, w3A, w2B, w3B, w2C, w3C;
     uint64_t sB, sC;
     asm("v_add_co_u32 %[w1A], vcc, %[w1A], %[m0A]\n\t"
         "v_add_co_u32_e64 %[w1B], %[sB], %[w1B], %[m0B]\n\t"
         "v_add_co_u32_e64 %[w1C], %[sC], %[w1C], %[m0C]\n\t"
-        "v_addc_co_u32 %[w2A], vcc, %[w2A], %[m1A], vcc\n\t"
-        "v_addc_co_u32_e64 %[w2B], %[sB], %[w2B], %[m1B], %[sB]\n\t"
-        "v_addc_co_u32_e64 %[w2C], %[sC], %[w2C], %[m1C], %[sC]\n\t"
-        "v_addc_co_u32 %[w3A], vcc, 0, %[w3A], vcc\n\t"                 // no carry out: a product is < 2^128
-        "v_addc_co_u32_e64 %[w3B], %[sB], 0, %[w3B], %[sB]\n\t"
-        "v_addc_co_u32_e64 %[w3C], %[sC], 0, %[w3C], %[sC]"
-        : [w1A] "+v"(w1A), [w2A] "+v"(w2A), [w3A] "+v"(w3A), [w1B] "+v"(w1B), [w2B] "+v"(w2B), [w3B] "+v"(w3B),
-          [w1C] "+v"(w1C), [w2C] "+v"(w2C), [w3C] "+v"(w3C), [sB] "=&s"(sB), [sC] "=&s"(sC)
+        "v_addc_co_u32 %[w2A], vcc, %[q0A], %[m1A], vcc\n\t"
+        "v_addc_co_u32_e64 %[w2B], %[sB], %[q0B], %[m1B], %[sB]\n\t"
+        "v_addc_co_u32_e64 %[w2C], %[sC], %[q0C], %[m1C], %[sC]\n\t"
+        "v_addc_co_u32 %[w3A], vcc, 0, %[q1A], vcc\n\t"                 // no carry out: a product is < 2^128
+        "v_addc_co_u32_e64 %[w3B], %[sB], 0, %[q1B], %[sB]\n\t"
+        "v_addc_co_u32_e64 %[w3C], %[sC], 0, %[q1C], %[sC]"
+        : [w1A] "+v"(w1A), [w2A] "=&v"(w2A), [w3A] "=&v"(w3A), [w1B] "+v"(w1B), [w2B] "=&v"(w2B), [w3B] "=&v"(w3B),
+          [w1C] "+v"(w1C), [w2C] "=&v"(w2C), [w3C] "=&v"(w3C), [sB] "=&s"(sB), [sC] "=&s"(sC)
         : [m0A] "v"((u32)midA), [m1A] "v"((u32)(midA >> 32)), [m0B] "v"((u32)midB), [m1B] "v"((u32)(midB >> 32)),
-          [m0C] "v"((u32)midC), [m1C] "v"((u32)(midC >> 32))
+          [m0C] "v"((u32)midC), [m1C] "v"((u32)(midC >> 32)),
+          [q0A] "v"((u32)p11A), [q1A] "v"((u32)(p11A >> 32)), [q0B] "v"((u32)p11B), [q1B] "v"((u32)(p11B >> 32)),
+          [q0C] "v"((u32)p11C), [q1C] "v"((u32)(p11C >> 32))
         : "vcc");
     // z = lo + hl * EPS (mod 2^64), carry c
     const gl_t loA = glx_mk64((u32)p00A, w1A), loB = glx_mk64((u32)p00B, w1B), loC = glx_mk64((u32)p00C, w1C);
@@ -167,14 +169,14 @@ __device__ __forceinline__ gl_t glx_mul(gl_t a, gl_t b) {
         : "=&v"(p00), "=&v"(mid), "=&v"(p11), "=&s"(cm)
         : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
         : "vcc");
-    u32 w1 = (u32)(p00 >> 32), w2 = (u32)p11, w3 = (u32)(p11 >> 32);
+    u32 w1 = (u32)(p00 >> 32), w2, w3;
     asm("v_add_co_u32 %[w1], vcc, %[w1], %[m0]\n\t"
         "s_nop 1\n\t"
-        "v_addc_co_u32 %[w2], vcc, %[w2], %[m1], vcc\n\t"
+        "v_addc_co_u32 %[w2], vcc, %[q0], %[m1], vcc\n\t"
         "s_nop 1\n\t"
-        "v_addc_co_u32 %[w3], vcc, 0, %[w3], vcc"
-        : [w1] "+v"(w1), [w2] "+v"(w2), [w3] "+v"(w3)
-        : [m0] "v"((u32)mid), [m1] "v"((u32)(mid >> 32))
+        "v_addc_co_u32 %[w3], vcc, 0, %[q1], vcc"
+        : [w1] "+v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3)
+        : [m0] "v"((u32)mid), [m1] "v"((u32)(mid >> 32)), [q0] "v"((u32)p11), [q1] "v"((u32)(p11 >> 32))
         : "vcc");
     const gl_t lo = glx_mk64((u32)p00, w1);
     gl_t z;
