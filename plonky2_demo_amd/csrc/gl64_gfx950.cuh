@@ -223,6 +223,12 @@ __device__ __forceinline__ gl_t glx_mad_k(uint32_t x, uint32_t c /* a constant a
     asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(x), "i"(c), "s"(k) : "vcc");
     return r;
 }
+// acc + x * c (mod 2^64) for a compile-time c in [0, 64], kept ONE multiply-add: written in C the compiler turns c = 2, 16 into a
+// 64-bit shift-add, which first needs x zero-extended into a register pair (two moves per term)
+__device__ __forceinline__ gl_t glx_mac_c(gl_t acc, uint32_t x, uint32_t c /* a constant after inlining and unrolling */) {
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "i"(c) : "vcc");
+    return acc;
+}
 // lo + top * EPS (mod p) with one fix-up, valid while lo + top * EPS < 2^65 - 2^32 (goldilocks_field.rs:346-351 reduce96):
 // v_mad_u64_u32 does the multiply by EPS, the 64-bit add and the carry in one instruction
 __device__ __forceinline__ gl_t glx_reduce96(gl_t lo, uint32_t top) {
@@ -459,6 +465,7 @@ template <bool CANON>
 __device__ gl_t glx_mul(gl_t a, gl_t b);
 __device__ gl_t glx_reduce96(gl_t lo, uint32_t top);
 __device__ gl_t glx_mad_k(uint32_t x, uint32_t c, uint64_t k);
+__device__ gl_t glx_mac_c(gl_t acc, uint32_t x, uint32_t c);
 __device__ gl_t glx_canon(gl_t x);
 __device__ gl_t glx_add_eps_if(gl_t z, uint32_t bit);
 __device__ gl_t glx_add_cc(gl_t a, gl_t b);

@@ -246,7 +246,7 @@ __device__ __forceinline__ void psd_partial_group(gl_t (&s)[12], int g, const gl
     const uint32_t d0l = (uint32_t)d0, d0h = (uint32_t)(d0 >> 32);
     gl_t al = glx_mad_k(d0l, 25u, (uint64_t)(uint32_t)K[0]), ah = glx_mad_k(d0h, 25u, K[0] >> 32);      // M[0][0]
 #pragma unroll
-    for (int i = 0; i < 12; i++) { const uint32_t c = psd_mds_entry(0, i); al += (gl_t)lo[i] * c; ah += (gl_t)hi[i] * c; }
+    for (int i = 0; i < 12; i++) { al = glx_mac_c(al, lo[i], psd_mds_entry(0, i)); ah = glx_mac_c(ah, hi[i], psd_mds_entry(0, i)); }
     const gl_t a1 = psd_acc_reduce(al, ah);
     a[1] = a1;
     const gl_t d1 = gl_sub(psd_sbox(SUBST ? in[1] : a1), a1);
@@ -322,14 +322,14 @@ __device__ __forceinline__ gl_t psd_coop_permute(gl_t s, const int l) {
         const uint32_t lo = (uint32_t)s, hi = (uint32_t)(s >> 32);
         gl_t al = 0, ah = 0;
         if (r + 1 < 8 + POSEIDON_PARTIAL_ROUNDS) { const gl_t c = rc[12 * (r + 1) + lc]; al = (uint32_t)c; ah = c >> 32; }
-        al += (gl_t)lo * circ[0]; ah += (gl_t)hi * circ[0];
+        al = glx_mac_c(al, lo, 17u); ah = glx_mac_c(ah, hi, 17u);      // circ[0]; multiply-adds, not shift-adds (glx_mac_c)
 #pragma unroll
         for (int i = 1; i < 12; i++) {
             int src = lc + i; src -= (src >= 12) ? 12 : 0;
             const int addr = (row + src) << 2;
             const uint32_t lo_i = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)lo);
             const uint32_t hi_i = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)hi);
-            al += (gl_t)lo_i * circ[i]; ah += (gl_t)hi_i * circ[i];
+            al = glx_mac_c(al, lo_i, circ[i]); ah = glx_mac_c(ah, hi_i, circ[i]);
         }
         if (l == 0) { al += (gl_t)lo * 8; ah += (gl_t)hi * 8; }   // MDS_MATRIX_DIAG[0] = 8
         s = psd_acc_reduce(al, ah);
