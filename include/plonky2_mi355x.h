@@ -64,7 +64,8 @@ typedef struct gl_proof gl_proof;      /* ProofWithPublicInputs + the prover's i
  * 380-440) besides the constants/sigma value columns.  Gate types: 0 Noop, 1 Constant, 2 PublicInput,
  * 3 Arithmetic(20 ops), 4 Poseidon -- the gate set of the matmul demo circuit -- and 5 BaseSumGate<2> with the 63 limbs
  * of BaseSumGate::new_from_config (gates/base_sum.rs:31-35; range_check / split_le), 6 LookupGate and 7 LookupTableGate
- * (the lookup argument, several tables: fields at the end of this struct; phase API: the *_lookups variants); `gate_types` is the list
+ * (the lookup argument, several tables: fields at the end of this struct; phase API: the *_lookups variants), 8 ExponentiationGate
+ * with the 66 power bits of new_from_config (gates/exponentiation.rs:43-53; CircuitBuilder::exp); `gate_types` is the list
  * `common_data.gates` (sorted by degree, id) and the group arrays are `selectors_info`
  * (plonky2/src/gates/selectors.rs:17-26). */
 typedef struct gl_circuit_desc {

@@ -74,6 +74,7 @@ struct CircuitData {
     std::vector<LookupSlot> lookup_slots;
     struct SplitRecipe { Target integer; std::vector<size_t> rows; };
     std::vector<SplitRecipe> split_ops;                 // BaseSumGate rows: sums from the integer, limbs from the sums
+    std::vector<size_t> exp_rows;                       // ExponentiationGate rows (one ExponentiationGenerator each)
     size_t pi_row = 0;
     struct ConstantWire { size_t row, wire; u64 value; };
     std::vector<ConstantWire> constant_wires;           // ConstantGenerator outputs: (row, wire column, value), one ConstantGate per two constants
@@ -239,6 +240,20 @@ struct CircuitBuilder {
         return bits;
     }
     void range_check(Target x, size_t n_log) { (void)split_le(x, n_log); }
+
+    // exp_from_bits / exp (gadgets/arithmetic.rs:240-272): ONE ExponentiationGate row of 66 power bits, the bits beyond the exponent's
+    // tied to _false(); the gate's ExponentiationGenerator (exponentiation.rs:233-280) fills the intermediate values and the output
+    std::vector<size_t> exp_rows;
+    Target exp_from_bits(Target base, const std::vector<Target>& exponent_bits) {
+        assert(exponent_bits.size() <= EXP_POWER_BITS);
+        Target f = zero();                                        // self._false()
+        const size_t row = add_gate(GATE_EXPONENTIATION);
+        connect(base, Target::wire(row, 0));
+        for (size_t i = 0; i < EXP_POWER_BITS; i++) connect(i < exponent_bits.size() ? exponent_bits[i] : f, Target::wire(row, 1 + i));
+        exp_rows.push_back(row);
+        return Target::wire(row, 1 + EXP_POWER_BITS);
+    }
+    Target exp(Target base, Target exponent, size_t num_bits) { return exp_from_bits(base, split_le(exponent, num_bits)); }
 
     // hash_n_to_hash_no_pad in circuit (hashing.rs:24-59) with PoseidonGate routing (poseidon.rs:724-751)
     std::array<Target, 4> hash_public_inputs(const std::vector<Target>& inputs) {
@@ -432,6 +447,7 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
     cd.arith_ops = b.arith_ops;
     cd.poseidon_rows = b.poseidon_rows;
     for (auto& so : b.split_ops) cd.split_ops.push_back({so.integer, so.rows});
+    cd.exp_rows = b.exp_rows;
     for (auto& lr : b.lookup_rows) cd.lookup_rows.push_back({lr.last_lu_gate, lr.last_lut_gate, lr.first_lut_gate});
     cd.lut_to_lookups = b.lut_to_lookups;
     for (auto& ls : b.lookup_slots) cd.lookup_slots.push_back({ls.row, ls.slot, ls.lut});
@@ -527,6 +543,13 @@ static inline CircuitData build_test_circuit(int kind, size_t param, unsigned th
         b.public_inputs.insert(b.public_inputs.end(), outs.begin(), outs.end());
         if (kind == 10) b.public_inputs.push_back(b.add_t(outs[0], outs[param]));
         cd.a_targets = ins;
+    } else if (kind == 13) {
+        // gadgets/arithmetic.rs:268-272 exp(base, exponent, num_bits = param): public inputs base, exponent, base^exponent; the exponent is
+        // split by a BaseSumGate<2>, the power taken by an ExponentiationGate (the first gate of degree 4 in these circuits)
+        Target base = b.add_virtual_target(), e = b.add_virtual_target();
+        Target r = b.exp(base, e, param);
+        b.public_inputs = {base, e, r};
+        cd.a_targets = {base, e};
     } else if (kind == 7) {
         // plonky2/examples/range_check.rs:20-24: the value is a public input and is range-checked to `param` (6) bits
         Target value = b.add_virtual_target();
@@ -612,7 +635,7 @@ static inline Witness generate_witness(const CircuitData& cd, const std::vector<
     // The reference runs every generator once its dependencies are known (iop/generator.rs:19-98): a fixed point over the three
     // kinds of generator present here.  The order of generation cannot change a value.
     auto is_set = [&](const Target& t) { return set[rep(t)] != 0; };
-    std::vector<char> arith_done(cd.arith_ops.size(), 0), split_done(cd.split_ops.size(), 0), pos_done(cd.poseidon_rows.size(), 0);
+    std::vector<char> arith_done(cd.arith_ops.size(), 0), split_done(cd.split_ops.size(), 0), pos_done(cd.poseidon_rows.size(), 0), exp_done(cd.exp_rows.size(), 0);
     std::vector<u64> rowbuf(135);
     for (bool progress = true; progress;) {
         progress = false;
@@ -635,6 +658,22 @@ static inline Witness generate_witness(const CircuitData& cd, const std::vector<
             }
             assert(v == 0 && "Integer too large to fit in the BaseSumGates");
             split_done[k] = 1; progress = true;
+        }
+        for (size_t k = 0; k < cd.exp_rows.size(); k++) {     // ExponentiationGenerator (exponentiation.rs:233-280)
+            const size_t row = cd.exp_rows[k], n = EXP_POWER_BITS;
+            if (exp_done[k]) continue;
+            bool ready = is_set(Target::wire(row, 0));
+            for (size_t i = 0; i < n && ready; i++) ready = is_set(Target::wire(row, 1 + i));
+            if (!ready) continue;
+            const u64 base = get(Target::wire(row, 0));
+            u64 cur = 1;
+            for (size_t i = 0; i < n; i++) {
+                if (canon(get(Target::wire(row, 1 + (n - 1 - i)))) == 1) cur = mul(cur, base);
+                put(Target::wire(row, 2 + n + i), cur);
+                if (i + 1 == n) put(Target::wire(row, 1 + n), cur);
+                cur = mul(cur, cur);
+            }
+            exp_done[k] = 1; progress = true;
         }
         for (size_t k = 0; k < cd.poseidon_rows.size(); k++) {
             const size_t row = cd.poseidon_rows[k];

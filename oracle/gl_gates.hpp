@@ -30,7 +30,10 @@ template <class K> static inline K ksbox(K x) { K x2 = kmul(x, x), x4 = kmul(x2,
 
 // (the numbering is the product's gl_circuit_desc.gate_types: 5 = BaseSumGate<2> with the 63 limbs of new_from_config)
 //  6 = LookupGate (40 (input, output) slots), 7 = LookupTableGate (26 (input, output, multiplicity) slots) of ONE lookup table
-enum GateType { GATE_NOOP = 0, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON, GATE_BASE_SUM, GATE_LOOKUP, GATE_LOOKUP_TABLE, GATE_NUM_TYPES };
+//  8 = ExponentiationGate with the 66 power bits of new_from_config (gates/exponentiation.rs:43-53: min(routed - 2, (wires - 2) / 2))
+enum GateType { GATE_NOOP = 0, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON, GATE_BASE_SUM, GATE_LOOKUP, GATE_LOOKUP_TABLE, GATE_EXPONENTIATION,
+                GATE_NUM_TYPES };
+static const size_t EXP_POWER_BITS = 66;                 // wires: 0 base, 1..66 power bits (little-endian), 67 output, 68..133 intermediate values
 static const size_t LOOKUP_SLOTS = 40, LOOKUP_TABLE_SLOTS = 26;      // gates/lookup.rs:41-44 (routed / 2), gates/lookup_table.rs:47-50 (routed / 3)
 static const size_t NUM_COINS_LOOKUP = 4;                           // circuit_builder.rs:56-58: ChallengeA, ChallengeB, ChallengeAlpha, ChallengeDelta
 enum { LU_CH_A = 0, LU_CH_B = 1, LU_CH_ALPHA = 2, LU_CH_DELTA = 3 };
@@ -41,7 +44,8 @@ static const size_t UNUSED_SELECTOR = 0xFFFFFFFFull;     // selectors.rs:14
 static inline unsigned gate_degree(GateType g) {
     switch (g) { case GATE_NOOP: return 0; case GATE_CONSTANT: return 1; case GATE_PUBLIC_INPUT: return 1;
                  case GATE_ARITHMETIC: return 3; case GATE_BASE_SUM: return 2 /* base_sum.rs:139-141 */;
-                 case GATE_LOOKUP: case GATE_LOOKUP_TABLE: return 0 /* lookup.rs:131-133, lookup_table.rs:150-152 */; default: return 7; }
+                 case GATE_LOOKUP: case GATE_LOOKUP_TABLE: return 0 /* lookup.rs:131-133, lookup_table.rs:150-152 */;
+                 case GATE_EXPONENTIATION: return 4 /* exponentiation.rs:186-188 */; default: return 7; }
 }
 static inline std::string gate_id(GateType g) {           // Gate::id(): the sort key next to the degree
     switch (g) {
@@ -54,6 +58,8 @@ static inline std::string gate_id(GateType g) {           // Gate::id(): the sor
         // comparison against the other gate types of degree 0 ("LookupGate {" < "LookupTableGate {" < "NoopGate")
         case GATE_LOOKUP: return "LookupGate { num_slots: 40, lut: [";
         case GATE_LOOKUP_TABLE: return "LookupTableGate { num_slots: 26, lut: [";
+        case GATE_EXPONENTIATION:          // format!("{self:?}<D={D}>") (exponentiation.rs:75-77)
+            return "ExponentiationGate { num_power_bits: 66, _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>";
         default: return "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>";
     }
 }
@@ -61,6 +67,7 @@ static inline size_t gate_num_constraints(GateType g) {
     switch (g) { case GATE_NOOP: return 0; case GATE_CONSTANT: return 2; case GATE_PUBLIC_INPUT: return 4;
                  case GATE_ARITHMETIC: return 20; case GATE_BASE_SUM: return 1 + BASE_SUM_LIMBS /* base_sum.rs:144-146 */;
                  case GATE_LOOKUP: case GATE_LOOKUP_TABLE: return 0;          // "No main trace constraints for lookups" (lookup.rs:72-75)
+                 case GATE_EXPONENTIATION: return EXP_POWER_BITS + 1;          // exponentiation.rs:190-192
                  default: return 123; }   // poseidon.rs:403-409
 }
 
@@ -127,6 +134,17 @@ static inline void eval_base_sum(const K* w, K* out) {                          
     for (size_t i = BASE_SUM_LIMBS; i-- > 0;) computed = kadd(kadd(computed, computed), w[1 + i]);
     out[0] = ksub(computed, w[0]);
     for (size_t i = 0; i < BASE_SUM_LIMBS; i++) out[1 + i] = kmul(w[1 + i], ksub(w[1 + i], kconst<K>(1)));      // (limb - 0)(limb - 1)
+}
+template <class K>
+static inline void eval_exponentiation(const K* w, K* out) {                   // exponentiation.rs:88-124: square-and-multiply, bits big-endian
+    const size_t n = EXP_POWER_BITS;
+    const K base = w[0], one = kconst<K>(1);
+    for (size_t i = 0; i < n; i++) {
+        const K prev = i == 0 ? one : kmul(w[2 + n + i - 1], w[2 + n + i - 1]);
+        const K bit = w[1 + (n - 1 - i)];
+        out[i] = ksub(kmul(prev, kadd(kmul(bit, base), ksub(one, bit))), w[2 + n + i]);
+    }
+    out[n] = ksub(w[1 + n], w[2 + n + n - 1]);
 }
 template <class K>
 static inline void eval_poseidon(const K* w, K* out) {                          // poseidon.rs:113-191
@@ -210,6 +228,7 @@ static inline void evaluate_gate_constraints(const SelectorsInfo& si, size_t num
             case GATE_PUBLIC_INPUT: eval_public_input<K>(pi_hash, wires, tmp); break;
             case GATE_ARITHMETIC: eval_arithmetic<K>(gc, wires, tmp); break;
             case GATE_BASE_SUM: eval_base_sum<K>(wires, tmp); break;
+            case GATE_EXPONENTIATION: eval_exponentiation<K>(wires, tmp); break;
             default: eval_poseidon<K>(wires, tmp); break;
         }
         for (size_t j = 0; j < nc; j++) out[j] = kadd(out[j], kmul(filter, tmp[j]));

@@ -291,6 +291,7 @@ static void sink_common(ByteSink& o, const CommonData& cm) {
             case GATE_CONSTANT: o.word32(3); o.usize(c.num_constants); break;
             case GATE_NOOP: o.word32(9); break;
             case GATE_POSEIDON: o.word32(11); break;
+            case GATE_EXPONENTIATION: o.word32(5); o.usize(EXP_POWER_BITS); break;        // write_usize(num_power_bits) (exponentiation.rs:79-81)
             case GATE_BASE_SUM: o.word32(2); o.usize(BASE_SUM_LIMBS); break;              // BaseSumGate<2>: write_usize(num_limbs) (base_sum.rs:53-55)
             case GATE_LOOKUP: o.word32(6); o.usize(LOOKUP_SLOTS); sink_lut(o, cm.luts[li]); break;                    // lookup.rs:59-62
             case GATE_LOOKUP_TABLE: o.word32(7); o.usize(LOOKUP_TABLE_SLOTS); sink_lut(o, cm.luts[li]); o.usize(cm.last_lut_rows[li]); break;   // lookup_table.rs:70-74

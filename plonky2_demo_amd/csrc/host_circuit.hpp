@@ -26,7 +26,11 @@ static const gl_t POW2_GEN = 1753635133440165772ULL;
 inline gl_t root_of_unity(unsigned lg) { gl_t r = POW2_GEN; for (unsigned i = lg; i < 32; i++) r = gl_sqr(r); return gl_canon(r); }
 
 // gate type codes shared with the device kernels (order = the reference's sort by (degree, id))
-enum { G_NOOP = 0, G_CONSTANT = 1, G_PUBLIC_INPUT = 2, G_ARITHMETIC = 3, G_POSEIDON = 4, G_BASE_SUM = 5, G_LOOKUP = 6, G_LOOKUP_TABLE = 7 };
+enum { G_NOOP = 0, G_CONSTANT = 1, G_PUBLIC_INPUT = 2, G_ARITHMETIC = 3, G_POSEIDON = 4, G_BASE_SUM = 5, G_LOOKUP = 6, G_LOOKUP_TABLE = 7, G_EXPONENTIATION = 8,
+       G_LAST = G_EXPONENTIATION };
+// ExponentiationGate::new_from_config (gates/exponentiation.rs:43-53): min(routed - 2, (wires - 2) / 2) = 66 power bits; wires: 0 base,
+// 1..66 power bits (little-endian), 67 output, 68..133 intermediate values; 67 constraints of degree 4
+enum { EXP_POWER_BITS = 66 };
 enum { LOOKUP_SLOTS = 40, LOOKUP_TABLE_SLOTS = 26, NUM_COINS_LOOKUP = 4 };      // gates/lookup.rs:41-44, gates/lookup_table.rs:47-50, circuit_builder.rs:56-58
 enum { LU_CH_A = 0, LU_CH_B = 1, LU_CH_ALPHA = 2, LU_CH_DELTA = 3 };            // LookupChallenges (circuit_builder.rs:61-71)
 enum { LU_SEL_TRANS_SRE = 0, LU_SEL_TRANS_LDC = 1, LU_SEL_INIT_SRE = 2, LU_SEL_LAST_LDC = 3, LU_SEL_START_END = 4 };      // gates/selectors.rs:34-40

@@ -127,7 +127,7 @@ static int validate_desc(const gl_circuit_desc& d) {
     for (unsigned r = 0; r < d.num_fri_rounds; r++) { GL_REQUIRE(d.fri_arity_bits[r] == 4, GL_ERR_UNSUPPORTED, "FRI arity must be 16"); tot += 4; }
     GL_REQUIRE(tot <= d.degree_bits && d.degree_bits + d.rate_bits >= tot + d.cap_height, GL_ERR_ARG, "FRI total reduction arity is too large");   // circuit_builder.rs:977-980
     for (unsigned g = 0; g < d.num_gates; g++) {
-        GL_REQUIRE(d.gate_types[g] <= glhost::G_LOOKUP_TABLE, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable}");
+        GL_REQUIRE(d.gate_types[g] <= glhost::G_LAST, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable, Exponentiation}");
         GL_REQUIRE(d.gate_selector_index[g] < d.num_selectors && d.gate_group_start[g] <= g && g < d.gate_group_end[g] && d.gate_group_end[g] <= d.num_gates, GL_ERR_ARG, "bad selector group");
     }
     return GL_OK;

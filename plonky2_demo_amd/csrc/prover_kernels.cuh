@@ -384,6 +384,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
                 acc.add(T0, glx_sub_cc(computed, w[0]));
                 break;
             }
+            case 8: {   // ExponentiationGate, 66 power bits (gates/exponentiation.rs:196-228): square-and-multiply, bits big-endian; wires:
+                        // 0 base, 1..66 bits, 67 output, 68..133 intermediate values.  Three steps at a time (their six products in two groups).
+                const gl_t base = w[0];
+                const gl_t* iv = w + (size_t)68 * N;                 // intermediate value i at iv[i * N]
+                gl_t last = 1;                                       // intermediate value i - 1 (1 before the first step)
+#pragma unroll 1
+                for (int k = 0; k < 66; k += 3) {
+                    const gl_t v0 = iv[(size_t)k * N], v1 = iv[(size_t)(k + 1) * N], v2 = iv[(size_t)(k + 2) * N];
+                    const gl_t b0 = w[(size_t)(66 - k) * N], b1 = w[(size_t)(65 - k) * N], b2 = w[(size_t)(64 - k) * N];      // bit wire 1 + (65 - i)
+                    gl_t p0, p1, p2, m0, m1, m2;
+                    glx_mul3<true>(last, last, v0, v0, v1, v1, p0, p1, p2);            // prev_i = (intermediate value i - 1)^2
+                    if (k == 0) p0 = 1;
+                    glx_mul3<true>(b0, base, b1, base, b2, base, m0, m1, m2);          // bit base + (1 - bit)
+                    m0 = glx_add_cc(m0, glx_sub_cc(1, b0)); m1 = glx_add_cc(m1, glx_sub_cc(1, b1)); m2 = glx_add_cc(m2, glx_sub_cc(1, b2));
+                    glx_mul3<true>(p0, m0, p1, m1, p2, m2, p0, p1, p2);
+                    acc.add(T0 + k, glx_sub_cc(p0, v0)); acc.add(T0 + k + 1, glx_sub_cc(p1, v1)); acc.add(T0 + k + 2, glx_sub_cc(p2, v2));
+                    last = v2;
+                }
+                acc.add(T0 + 66, glx_sub_cc(w[(size_t)67 * N], last));
+                break;
+            }
             default: break;   // NoopGate
         }
         gl_t fs0, fs1, unused;

@@ -150,7 +150,7 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
                d.degree_bits >= 1 && d.degree_bits + d.rate_bits <= 32 && d.cap_height <= d.degree_bits + d.rate_bits && d.num_query_rounds >= 1,
                GL_ERR_ARG, "gl_verify: bad circuit description");
     for (unsigned g = 0; g < d.num_gates; g++)
-        GL_REQUIRE(d.gate_types[g] <= glhost::G_LOOKUP_TABLE && d.gate_selector_index[g] < d.num_selectors && d.gate_group_start[g] <= g && g < d.gate_group_end[g] && d.gate_group_end[g] <= d.num_gates,
+        GL_REQUIRE(d.gate_types[g] <= glhost::G_LAST && d.gate_selector_index[g] < d.num_selectors && d.gate_group_start[g] <= g && g < d.gate_group_end[g] && d.gate_group_end[g] <= d.num_gates,
                    GL_ERR_ARG, "gl_verify: bad gate / selector description");
     const size_t nch = 2, R = 80, W = 135, QF = 8, NPP = 9;            // partial products per challenge: ceil(80 / 8) - 1
     const size_t ncap = size_t(1) << d.cap_height, ncs = d.num_constants + R;
@@ -263,6 +263,17 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
                     for (int i = glhost::BASE_SUM_LIMBS; i-- > 0;) computed = e_add(e_add(computed, computed), wires[1 + i]);
                     tmp[0] = e_sub(computed, wires[0]);
                     for (int i = 0; i < glhost::BASE_SUM_LIMBS; i++) tmp[1 + i] = e_mul(wires[1 + i], e_sub(wires[1 + i], e_of(1)));
+                    break;
+                }
+                case glhost::G_EXPONENTIATION: {                                                                                                        // exponentiation.rs:88-124
+                    const int n = glhost::EXP_POWER_BITS;
+                    cnt = n + 1;
+                    for (int i = 0; i < n; i++) {                                                                                                        // square-and-multiply, bits big-endian
+                        const E prev = i == 0 ? e_of(1) : e_mul(wires[2 + n + i - 1], wires[2 + n + i - 1]);
+                        const E bit = wires[1 + (n - 1 - i)];
+                        tmp[i] = e_sub(e_mul(prev, e_add(e_mul(bit, wires[0]), e_sub(e_of(1), bit))), wires[2 + n + i]);
+                    }
+                    tmp[n] = e_sub(wires[1 + n], wires[2 + n + n - 1]);
                     break;
                 }
                 default: cnt = 123; poseidon_gate_constraints(wires.data(), tmp); break;

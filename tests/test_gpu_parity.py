@@ -882,6 +882,24 @@ def test_range_check_circuits_with_base_sum_gate(gpu, orc, bits, value):
     assert not cd.verify(bytes(bad))[0] and not oc.verify_bytes(bytes(bad), cd.constants_sigmas_cap, cd.circuit_digest)[0]
 
 
+@pytest.mark.parametrize("bits,base,exponent", [(10, 3, 1000), (64, 7, 2**63 + 5), (66, 5, P - 2), (66, P - 1, P - 1), (1, 9, 0), (7, 0, 5)])
+def test_exponentiation_gate_circuits(gpu, orc, bits, base, exponent):
+    # ExponentiationGate (gates/exponentiation.rs; 66 power bits, degree 4) behind CircuitBuilder::exp (gadgets/arithmetic.rs:240-272): the
+    # quotient kernel's case 8 (three square-and-multiply steps at a time).  GPU proof bytes == oracle's, both verifiers accept, the public
+    # output is base^exponent, a flipped intermediate-value opening is rejected by both.  PARITY UNPINNED against a Rust proof.
+    p, ctx = gpu
+    oc = orc.circuit_of_kind(13, bits, threads=8)
+    w = oc.witness(np.array([base, exponent], dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=bits)
+    gp = _prove_generic_and_compare(p, oc, w)
+    assert [int(x) for x in w.public_inputs()] == [base, exponent, pow(base, exponent, P)]
+    desc = oc.product_desc()
+    assert 8 in list(desc.gate_types)[:desc.num_gates]
+    cd = p.GenericCircuitData(desc, oc.constants_sigmas())
+    bad = bytearray(gp.to_bytes())
+    bad[3 * 16 * 32 + (desc.num_constants + 80) * 16 + 100 * 16] ^= 1      # an opened wire value (wire 100: an intermediate value)
+    assert not cd.verify(bytes(bad))[0] and not oc.verify_bytes(bytes(bad), cd.constants_sigmas_cap, cd.circuit_digest)[0]
+
+
 @pytest.mark.parametrize("kind,param,inputs", [
     (8, 2, [1, 2]),                                   # lookup_test.rs test_one_lookup
     (8, 50, list(range(3, 53))),                      # two LookupGate rows, the second one padded

@@ -273,6 +273,49 @@ def test_base_sum_gate_circuits_verify_natively_and_through_the_byte_form(orc, b
     assert e.value.code == 3
 
 
+@pytest.mark.parametrize("bits,base,exponent", [(10, 3, 1000), (64, 7, 2**63 + 5), (66, 5, 2**64 - 2**32 - 1), (1, 9, 1), (5, 0, 0)])
+def test_exponentiation_gate_circuits_verify_natively_and_through_the_byte_form(orc, bits, base, exponent):
+    # ExponentiationGate (gate type 8; gates/exponentiation.rs, 66 power bits from new_from_config, 67 constraints of degree 4) behind
+    # CircuitBuilder::exp (gadgets/arithmetic.rs:240-272: the exponent split by a BaseSumGate<2>, unused power bits tied to false):
+    # the oracle's proof of base^exponent is accepted by gl_verify, mutations get the oracle's verdict, the circuit data round-trips
+    # through the reference's byte form (gate tag 5, usize num_power_bits)
+    import ctypes
+    import plonky2_demo_amd as p
+    from plonky2_demo_amd import api
+    from plonky2_demo_amd._lib import lib, GL_OK
+    P = 2**64 - 2**32 + 1
+    oc = orc.circuit_of_kind(13, bits, threads=4)
+    w = oc.witness(np.array([base, exponent], dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=1)
+    assert [int(x) for x in w.public_inputs()] == [base, exponent, pow(base, exponent, P)]
+    proof = w.prove(threads=4).to_bytes()
+    desc = oc.product_desc()
+    gates = list(desc.gate_types)[:desc.num_gates]
+    assert gates.count(8) == 1 and gates.index(8) == len(gates) - 2 and gates[-1] == 4      # degree 4: between Arithmetic (3) and Poseidon (7)
+    cap, dig = np.ascontiguousarray(oc.constants_sigmas_cap), np.ascontiguousarray(oc.digest)
+    vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+
+    def native(by):
+        buf = np.frombuffer(by, dtype=np.uint8)
+        return lib.gl_verify(ctypes.byref(desc), vp(cap), vp(dig), vp(buf), buf.size) == GL_OK
+    assert native(proof), lib.gl_last_error()
+    common = api.common_data_to_bytes(desc)
+    assert common == oc.data_bytes(0)
+    d2, used = api.common_data_from_bytes(common)
+    assert used == len(common) and bytes(d2) == bytes(desc)
+    vd = api.verifier_data_to_bytes(desc, cap, dig)
+    assert vd == oc.data_bytes(1) and api.verify_bytes(vd, proof) == (True, "")
+    rng = np.random.default_rng(bits)
+    for _ in range(40):
+        bad = bytearray(proof)
+        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        assert native(bytes(bad)) == oc.verify_bytes(bytes(bad), cap, dig)[0]
+    i = common.index((5).to_bytes(4, "little") + (66).to_bytes(8, "little"))
+    bad = bytearray(common); bad[i + 4:i + 12] = (32).to_bytes(8, "little")
+    with pytest.raises(p.Plonky2Mi355xError) as e:
+        api.common_data_from_bytes(bytes(bad))
+    assert e.value.code == 3
+
+
 def lookup_outputs(kind, param, inputs):
     """Public inputs the oracle's lookup circuits (oracle/gl_circuit.hpp kinds 8-12) must produce, and their number of tables."""
     P = 2**64 - 2**32 + 1
