@@ -29,7 +29,7 @@ template <> inline Ext2 kconst<Ext2>(u64 c) { return Ext2{c, 0}; }
 template <class K> static inline K ksbox(K x) { K x2 = kmul(x, x), x4 = kmul(x2, x2), x3 = kmul(x, x2); return kmul(x3, x4); }
 
 // (the numbering is the product's gl_circuit_desc.gate_types: 5 = BaseSumGate<2> with the 63 limbs of new_from_config)
-//  6 = LookupGate (40 (input, output) slots), 7 = LookupTableGate (26 (input, output, multiplicity) slots) of ONE lookup table
+//  6 = LookupGate (40 (input, output) slots), 7 = LookupTableGate (26 (input, output, multiplicity) slots): one of each per lookup table
 //  8 = ExponentiationGate with the 66 power bits of new_from_config (gates/exponentiation.rs:43-53: min(routed - 2, (wires - 2) / 2))
 enum GateType { GATE_NOOP = 0, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON, GATE_BASE_SUM, GATE_LOOKUP, GATE_LOOKUP_TABLE, GATE_EXPONENTIATION,
                 GATE_NUM_TYPES };
