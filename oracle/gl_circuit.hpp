@@ -255,6 +255,37 @@ struct CircuitBuilder {
     }
     Target exp(Target base, Target exponent, size_t num_bits) { return exp_from_bits(base, split_le(exponent, num_bits)); }
 
+    // permute_swapped (hash/poseidon.rs:724-751): one PoseidonGate row; `swap` exchanges the first two digests of the input
+    std::array<Target, 12> permute_swapped(const std::array<Target, 12>& inputs, Target swap) {
+        size_t row = add_gate(GATE_POSEIDON);
+        poseidon_rows.push_back(row);
+        connect(swap, Target::wire(row, PoseidonWires::SWAP));
+        for (int i = 0; i < 12; i++) connect(inputs[i], Target::wire(row, PoseidonWires::INPUT + i));
+        std::array<Target, 12> out;
+        for (int i = 0; i < 12; i++) out[i] = Target::wire(row, PoseidonWires::OUTPUT + i);
+        return out;
+    }
+    // hash_or_noop (hash/hashing.rs:15-22)
+    std::array<Target, 4> hash_or_noop(const std::vector<Target>& inputs) {
+        if (inputs.size() <= 4) { Target z = zero(); std::array<Target, 4> h; h.fill(z); for (size_t i = 0; i < inputs.size(); i++) h[i] = inputs[i]; return h; }
+        return hash_public_inputs(inputs);        // hash_n_to_hash_no_pad: the same sponge
+    }
+    // verify_merkle_proof (hash/merkle_proofs.rs:78-150) against a ROOT (a cap of one digest: cap_index = le_sum of no bits = zero and
+    // random_access over a one-element list is the element itself, gadgets/random_access.rs:17-20): the leaf hash, one swapped permutation
+    // per level on (state || sibling || zeros), the result tied to the root
+    void verify_merkle_proof(const std::vector<Target>& leaf_data, const std::vector<Target>& leaf_index_bits, const std::array<Target, 4>& root,
+                             const std::vector<std::array<Target, 4>>& siblings) {
+        Target z = zero();
+        std::array<Target, 4> state = hash_or_noop(leaf_data);
+        for (size_t l = 0; l < siblings.size(); l++) {
+            std::array<Target, 12> in; in.fill(z);
+            for (int i = 0; i < 4; i++) { in[i] = state[i]; in[4 + i] = siblings[l][i]; }
+            auto out = permute_swapped(in, leaf_index_bits[l]);
+            for (int i = 0; i < 4; i++) state[i] = out[i];
+        }
+        for (int i = 0; i < 4; i++) connect(root[i], state[i]);
+    }
+
     // hash_n_to_hash_no_pad in circuit (hashing.rs:24-59) with PoseidonGate routing (poseidon.rs:724-751)
     std::array<Target, 4> hash_public_inputs(const std::vector<Target>& inputs) {
         Target z = zero();
@@ -542,6 +573,22 @@ static inline CircuitData build_test_circuit(int kind, size_t param, unsigned th
         b.public_inputs = ins;
         b.public_inputs.insert(b.public_inputs.end(), outs.begin(), outs.end());
         if (kind == 10) b.public_inputs.push_back(b.add_t(outs[0], outs[param]));
+        cd.a_targets = ins;
+    } else if (kind == 14) {
+        // hash/merkle_proofs.rs:78-150, as in its test_recursive_merkle_proof (:175-220) with a root instead of a cap: a 5-element leaf at a
+        // `param`-bit index, `param` sibling digests, the root.  Inputs: leaf (5), index, siblings (4 x param), root (4); public inputs: the
+        // root and the index.  The PoseidonGates run with swap = the index bits (the demo circuit only ever has swap = 0).
+        std::vector<Target> leaf, ins;
+        for (int i = 0; i < 5; i++) leaf.push_back(b.add_virtual_target());
+        Target index = b.add_virtual_target();
+        std::vector<std::array<Target, 4>> sibs(param);
+        for (auto& sb : sibs) for (auto& t : sb) t = b.add_virtual_target();
+        std::array<Target, 4> root; for (auto& t : root) t = b.add_virtual_target();
+        b.verify_merkle_proof(leaf, b.split_le(index, param), root, sibs);
+        ins = leaf; ins.push_back(index);
+        for (auto& sb : sibs) for (auto& t : sb) ins.push_back(t);
+        for (auto& t : root) ins.push_back(t);
+        b.public_inputs = {root[0], root[1], root[2], root[3], index};
         cd.a_targets = ins;
     } else if (kind == 13) {
         // gadgets/arithmetic.rs:268-272 exp(base, exponent, num_bits = param): public inputs base, exponent, base^exponent; the exponent is

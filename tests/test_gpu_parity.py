@@ -882,6 +882,24 @@ def test_range_check_circuits_with_base_sum_gate(gpu, orc, bits, value):
     assert not cd.verify(bytes(bad))[0] and not oc.verify_bytes(bytes(bad), cd.constants_sigmas_cap, cd.circuit_digest)[0]
 
 
+@pytest.mark.parametrize("height,index", [(0, 0), (1, 1), (5, 13), (5, 31), (8, 170), (12, 4095)])
+def test_merkle_proof_verification_circuits(gpu, orc, height, index):
+    # CircuitBuilder::verify_merkle_proof (hash/merkle_proofs.rs:78-150): PoseidonGate rows with swap = 1 (the delta wires of
+    # gates/poseidon.rs:113-135 are non-zero), which the demo circuit never produces: the quotient kernel's Poseidon part, the openings and
+    # both verifiers on them.  GPU proof bytes == the oracle's.  PARITY UNPINNED against a Rust proof.
+    from test_verifier import merkle_proof_circuit_inputs
+    p, ctx = gpu
+    oc = orc.circuit_of_kind(14, height, threads=8)
+    a, root = merkle_proof_circuit_inputs(orc, height, index)
+    w = oc.witness(a, np.zeros(0, dtype=np.uint64), filler_seed=height)
+    _prove_generic_and_compare(p, oc, w)
+    assert [int(x) for x in w.public_inputs()] == [int(x) for x in root] + [index]
+    rows = oc.row_gates()
+    wires = w.wires()
+    swaps = [int(wires[24][r]) for r in range(len(rows)) if rows[r] == 4]      # PoseidonGate::WIRE_SWAP = 24
+    assert sum(swaps) == bin(index).count("1")
+
+
 @pytest.mark.parametrize("bits,base,exponent", [(10, 3, 1000), (64, 7, 2**63 + 5), (66, 5, P - 2), (66, P - 1, P - 1), (1, 9, 0), (7, 0, 5)])
 def test_exponentiation_gate_circuits(gpu, orc, bits, base, exponent):
     # ExponentiationGate (gates/exponentiation.rs; 66 power bits, degree 4) behind CircuitBuilder::exp (gadgets/arithmetic.rs:240-272): the

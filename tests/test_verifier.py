@@ -316,6 +316,43 @@ def test_exponentiation_gate_circuits_verify_natively_and_through_the_byte_form(
     assert e.value.code == 3
 
 
+def merkle_proof_circuit_inputs(orc, height, index, seed=7):
+    """Inputs of the oracle's in-circuit Merkle proof verification (kind 14): leaf (5), index, siblings (4 x height), root (4)."""
+    from oracle_lib import rand_field
+    leaves = rand_field(seed, (1 << height, 5))
+    tree = orc.merkle(leaves, 0)
+    root = tree.cap[0]
+    a = np.concatenate([leaves[index], np.array([index], dtype=np.uint64), tree.prove(index).reshape(-1), root])
+    return a, root
+
+
+@pytest.mark.parametrize("height,index", [(0, 0), (1, 1), (5, 13), (5, 31), (8, 170)])
+def test_merkle_proof_circuits_verify_natively(orc, height, index):
+    # CircuitBuilder::verify_merkle_proof (hash/merkle_proofs.rs:78-150; its test_recursive_merkle_proof, with a root for the cap): the
+    # leaf hash and one SWAPPED PoseidonGate per level, swap = the index bits from a BaseSumGate<2> -- the demo circuit only ever runs the
+    # gate with swap = 0.  The oracle's proof is accepted by gl_verify and mutations get the oracle's verdict.
+    import ctypes
+    from plonky2_demo_amd._lib import lib, GL_OK
+    oc = orc.circuit_of_kind(14, height, threads=4)
+    a, root = merkle_proof_circuit_inputs(orc, height, index)
+    w = oc.witness(a, np.zeros(0, dtype=np.uint64), filler_seed=1)
+    assert [int(x) for x in w.public_inputs()] == [int(x) for x in root] + [index]
+    proof = w.prove(threads=4).to_bytes()
+    desc = oc.product_desc()
+    cap, dig = np.ascontiguousarray(oc.constants_sigmas_cap), np.ascontiguousarray(oc.digest)
+    vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+
+    def native(by):
+        buf = np.frombuffer(by, dtype=np.uint8)
+        return lib.gl_verify(ctypes.byref(desc), vp(cap), vp(dig), vp(buf), buf.size) == GL_OK
+    assert native(proof), lib.gl_last_error()
+    rng = np.random.default_rng(height)
+    for _ in range(30):
+        bad = bytearray(proof)
+        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        assert native(bytes(bad)) == oc.verify_bytes(bytes(bad), cap, dig)[0]
+
+
 def lookup_outputs(kind, param, inputs):
     """Public inputs the oracle's lookup circuits (oracle/gl_circuit.hpp kinds 8-12) must produce, and their number of tables."""
     P = 2**64 - 2**32 + 1
