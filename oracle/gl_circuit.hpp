@@ -574,6 +574,19 @@ static inline CircuitData build_test_circuit(int kind, size_t param, unsigned th
         b.public_inputs.insert(b.public_inputs.end(), outs.begin(), outs.end());
         if (kind == 10) b.public_inputs.push_back(b.add_t(outs[0], outs[param]));
         cd.a_targets = ins;
+    } else if (kind == 15) {
+        // every supported gate type in one circuit (11 gate types: Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Exponentiation,
+        // and a LookupGate + LookupTableGate for each of two tables): several selector groups.  Inputs: x (< 256), y (< 2^param, param <= 16).
+        // out0 = table0[x], out1 = table1[x], s = out0 + out1, r = (s + 3)^y, y range-checked to `param` bits; public inputs x, y, s, r.
+        std::vector<std::pair<uint16_t, uint16_t>> t0, t1;
+        for (unsigned i = 0; i < 256; i++) { t0.push_back({(uint16_t)i, (uint16_t)((7 * i + 1) % 256)}); t1.push_back({(uint16_t)i, (uint16_t)((3 * i * i + 5 * i + 7) % 256)}); }
+        const size_t i0 = b.add_lookup_table_from_pairs(t0), i1 = b.add_lookup_table_from_pairs(t1);
+        Target x = b.add_virtual_target(), y = b.add_virtual_target();
+        Target o0 = b.add_lookup_from_index(x, i0), o1 = b.add_lookup_from_index(x, i1);
+        Target sum = b.add_t(o0, o1);
+        Target r = b.exp(b.add_const(sum, 3), y, param);
+        b.public_inputs = {x, y, sum, r};
+        cd.a_targets = {x, y};
     } else if (kind == 14) {
         // hash/merkle_proofs.rs:78-150, as in its test_recursive_merkle_proof (:175-220) with a root instead of a cap: a 5-element leaf at a
         // `param`-bit index, `param` sibling digests, the root.  Inputs: leaf (5), index, siblings (4 x param), root (4); public inputs: the
@@ -679,9 +692,20 @@ static inline Witness generate_witness(const CircuitData& cd, const std::vector<
     for (size_t i = 0; i < a.size(); i++) put(cd.a_targets[i], a[i]);
     for (size_t i = 0; i < b.size(); i++) put(cd.b_targets[i], b[i]);
     for (auto& cw : cd.constant_wires) put(Target::wire(cw.row, cw.wire), cw.value);
-    // The reference runs every generator once its dependencies are known (iop/generator.rs:19-98): a fixed point over the three
-    // kinds of generator present here.  The order of generation cannot change a value.
+    // The reference runs every generator once its dependencies are known (iop/generator.rs:19-98): ONE fixed point over all the kinds
+    // of generator present here (a lookup output may feed arithmetic, an exponentiation, a hash ...).  The order cannot change a value.
     auto is_set = [&](const Target& t) { return set[rep(t)] != 0; };
+    // LookupTableGenerator (lookup_table.rs:175-203): no dependencies; table entries fill the LUT rows upside down, padded with zeros
+    for (size_t li = 0; li < cd.lookup_rows.size(); li++) {
+        auto& lr = cd.lookup_rows[li]; auto& lut = cd.common.luts[li];
+        for (size_t row = lr.last_lut_gate; row <= lr.first_lut_gate; row++)
+            for (size_t sl = 0; sl < LOOKUP_TABLE_SLOTS; sl++) {
+                const size_t entry = (lr.first_lut_gate - row) * LOOKUP_TABLE_SLOTS + sl;
+                put(Target::wire(row, 3 * sl), entry < lut.size() ? lut[entry].first : 0);
+                put(Target::wire(row, 3 * sl + 1), entry < lut.size() ? lut[entry].second : 0);
+            }
+    }
+    std::vector<char> lk_done(cd.lookup_slots.size(), 0);      // LookupGenerator (lookup.rs:151-175): one per slot, needs its looking input
     std::vector<char> arith_done(cd.arith_ops.size(), 0), split_done(cd.split_ops.size(), 0), pos_done(cd.poseidon_rows.size(), 0), exp_done(cd.exp_rows.size(), 0);
     std::vector<u64> rowbuf(135);
     for (bool progress = true; progress;) {
@@ -706,6 +730,18 @@ static inline Witness generate_witness(const CircuitData& cd, const std::vector<
             assert(v == 0 && "Integer too large to fit in the BaseSumGates");
             split_done[k] = 1; progress = true;
         }
+        for (size_t k = 0; k < cd.lookup_slots.size(); k++) {
+            auto& ls = cd.lookup_slots[k];
+            Target tin = Target::wire(ls.row, 2 * ls.slot);
+            if (lk_done[k] || !is_set(tin)) continue;
+            const u64 v = canon(get(tin));
+            auto& lut = cd.common.luts[ls.lut];
+            size_t idx = 0;
+            if (v < lut.size() && lut[v].first == v) idx = v;
+            else { while (idx < lut.size() && lut[idx].first != v) idx++; assert(idx < lut.size() && "Incorrect input value provided"); }
+            put(Target::wire(ls.row, 2 * ls.slot + 1), lut[idx].second);
+            lk_done[k] = 1; progress = true;
+        }
         for (size_t k = 0; k < cd.exp_rows.size(); k++) {     // ExponentiationGenerator (exponentiation.rs:233-280)
             const size_t row = cd.exp_rows[k], n = EXP_POWER_BITS;
             if (exp_done[k]) continue;
@@ -721,55 +757,6 @@ static inline Witness generate_witness(const CircuitData& cd, const std::vector<
                 cur = mul(cur, cur);
             }
             exp_done[k] = 1; progress = true;
-        }
-        for (size_t k = 0; k < cd.poseidon_rows.size(); k++) {
-            const size_t row = cd.poseidon_rows[k];
-            if (pos_done[k]) continue;
-            bool ready = is_set(Target::wire(row, PoseidonWires::SWAP));
-            for (int i = 0; i < 12 && ready; i++) ready = is_set(Target::wire(row, PoseidonWires::INPUT + i));
-            if (!ready) continue;
-            u64 in[12];
-            for (int i = 0; i < 12; i++) in[i] = get(Target::wire(row, PoseidonWires::INPUT + i));
-            u64 swap = get(Target::wire(row, PoseidonWires::SWAP));
-            poseidon_gate_witness(in, swap, rowbuf.data());
-            for (int c = PoseidonWires::DELTA; c < PoseidonWires::END; c++) put(Target::wire(row, c), rowbuf[c]);
-            for (int i = 0; i < 12; i++) put(Target::wire(row, PoseidonWires::OUTPUT + i), rowbuf[PoseidonWires::OUTPUT + i]);
-            pos_done[k] = 1; progress = true;
-        }
-    }
-    // LookupTableGenerator (lookup_table.rs:175-203): no dependencies; table entries fill the LUT rows upside down, padded with zeros
-    for (size_t li = 0; li < cd.lookup_rows.size(); li++) {
-        auto& lr = cd.lookup_rows[li]; auto& lut = cd.common.luts[li];
-        for (size_t row = lr.last_lut_gate; row <= lr.first_lut_gate; row++)
-            for (size_t sl = 0; sl < LOOKUP_TABLE_SLOTS; sl++) {
-                const size_t entry = (lr.first_lut_gate - row) * LOOKUP_TABLE_SLOTS + sl;
-                put(Target::wire(row, 3 * sl), entry < lut.size() ? lut[entry].first : 0);
-                put(Target::wire(row, 3 * sl + 1), entry < lut.size() ? lut[entry].second : 0);
-            }
-    }
-    // LookupGenerator (lookup.rs:151-175) needs the looking inputs, which other generators may produce: second fixed point
-    std::vector<char> lk_done(cd.lookup_slots.size(), 0);
-    for (bool progress = true; progress;) {
-        progress = false;
-        for (size_t k = 0; k < cd.lookup_slots.size(); k++) {
-            auto& ls = cd.lookup_slots[k];
-            Target tin = Target::wire(ls.row, 2 * ls.slot);
-            if (lk_done[k] || !is_set(tin)) continue;
-            const u64 v = canon(get(tin));
-            auto& lut = cd.common.luts[ls.lut];
-            size_t idx = 0;
-            if (v < lut.size() && lut[v].first == v) idx = v;
-            else { while (idx < lut.size() && lut[idx].first != v) idx++; assert(idx < lut.size() && "Incorrect input value provided"); }
-            put(Target::wire(ls.row, 2 * ls.slot + 1), lut[idx].second);
-            lk_done[k] = 1; progress = true;
-        }
-        // a lookup output may feed arithmetic / hashing: let those run again
-        for (size_t k = 0; k < cd.arith_ops.size(); k++) {
-            auto& op = cd.arith_ops[k];
-            Target t0 = Target::wire(op.row, 4 * op.slot), t1 = Target::wire(op.row, 4 * op.slot + 1), t2 = Target::wire(op.row, 4 * op.slot + 2);
-            if (arith_done[k] || !is_set(t0) || !is_set(t1) || !is_set(t2)) continue;
-            put(Target::wire(op.row, 4 * op.slot + 3), add(mul(mul(get(t0), get(t1)), op.c0), mul(get(t2), op.c1)));
-            arith_done[k] = 1; progress = true;
         }
         for (size_t k = 0; k < cd.poseidon_rows.size(); k++) {
             const size_t row = cd.poseidon_rows[k];

@@ -882,6 +882,19 @@ def test_range_check_circuits_with_base_sum_gate(gpu, orc, bits, value):
     assert not cd.verify(bytes(bad))[0] and not oc.verify_bytes(bytes(bad), cd.constants_sigmas_cap, cd.circuit_digest)[0]
 
 
+@pytest.mark.parametrize("bits,x,y", [(9, 200, 300), (16, 255, 65535), (1, 0, 0)])
+def test_a_circuit_with_every_supported_gate_type(gpu, orc, bits, x, y):
+    # 11 gate types in three selector groups (oracle kind 15: two lookup tables, BaseSum<2>, Arithmetic, Exponentiation, Poseidon, ...):
+    # the quotient kernels' filters across several groups, GL_MAX_GATES-sized gate arrays, 11 constant columns.  GPU bytes == oracle bytes.
+    p, ctx = gpu
+    oc = orc.circuit_of_kind(15, bits, threads=8)
+    w = oc.witness(np.array([x, y], dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=bits)
+    _prove_generic_and_compare(p, oc, w)
+    s = (7 * x + 1) % 256 + (3 * x * x + 5 * x + 7) % 256
+    assert [int(v) for v in w.public_inputs()] == [x, y, s, pow(s + 3, y, P)]
+    assert oc.product_desc().num_selectors == 3
+
+
 @pytest.mark.parametrize("height,index", [(0, 0), (1, 1), (5, 13), (5, 31), (8, 170), (12, 4095)])
 def test_merkle_proof_verification_circuits(gpu, orc, height, index):
     # CircuitBuilder::verify_merkle_proof (hash/merkle_proofs.rs:78-150): PoseidonGate rows with swap = 1 (the delta wires of

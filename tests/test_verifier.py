@@ -316,6 +316,42 @@ def test_exponentiation_gate_circuits_verify_natively_and_through_the_byte_form(
     assert e.value.code == 3
 
 
+def test_a_circuit_with_every_supported_gate_type_verifies_natively_and_through_the_byte_form(orc):
+    # 11 gate types in three selector groups (two tables' LookupGate / LookupTableGate, Noop, Constant, PublicInput, BaseSum<2>, Arithmetic,
+    # Exponentiation, Poseidon), 11 constant columns: the filters of several groups with the unused-selector factor (gate.rs:277-284),
+    # the group arrays of the description, the byte form of SelectorsInfo with three groups
+    import ctypes
+    from plonky2_demo_amd import api
+    from plonky2_demo_amd._lib import lib, GL_OK
+    P = 2**64 - 2**32 + 1
+    oc = orc.circuit_of_kind(15, 9, threads=4)
+    x, y = 200, 300
+    w = oc.witness(np.array([x, y], dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=2)
+    s = (7 * x + 1) % 256 + (3 * x * x + 5 * x + 7) % 256
+    assert [int(v) for v in w.public_inputs()] == [x, y, s, pow(s + 3, y, P)]
+    proof = w.prove(threads=4).to_bytes()
+    desc = oc.product_desc()
+    assert desc.num_gates == 11 and desc.num_selectors == 3 and sorted(list(desc.gate_types)[:11]) == [0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8]
+    cap, dig = np.ascontiguousarray(oc.constants_sigmas_cap), np.ascontiguousarray(oc.digest)
+    vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+
+    def native(by):
+        buf = np.frombuffer(by, dtype=np.uint8)
+        return lib.gl_verify(ctypes.byref(desc), vp(cap), vp(dig), vp(buf), buf.size) == GL_OK
+    assert native(proof), lib.gl_last_error()
+    common = api.common_data_to_bytes(desc)
+    assert common == oc.data_bytes(0)
+    d2, used = api.common_data_from_bytes(common)
+    for t in range(2):
+        d2.last_lu_row[t] = desc.last_lu_row[t]
+    assert used == len(common) and bytes(d2) == bytes(desc)
+    rng = np.random.default_rng(15)
+    for _ in range(40):
+        bad = bytearray(proof)
+        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        assert native(bytes(bad)) == oc.verify_bytes(bytes(bad), cap, dig)[0]
+
+
 def merkle_proof_circuit_inputs(orc, height, index, seed=7):
     """Inputs of the oracle's in-circuit Merkle proof verification (kind 14): leaf (5), index, siblings (4 x height), root (4)."""
     from oracle_lib import rand_field
