@@ -65,7 +65,8 @@ typedef struct gl_proof gl_proof;      /* ProofWithPublicInputs + the prover's i
  * 3 Arithmetic(20 ops), 4 Poseidon -- the gate set of the matmul demo circuit -- and 5 BaseSumGate<2> with the 63 limbs
  * of BaseSumGate::new_from_config (gates/base_sum.rs:31-35; range_check / split_le), 6 LookupGate and 7 LookupTableGate
  * (the lookup argument, several tables: fields at the end of this struct; phase API: the *_lookups variants), 8 ExponentiationGate
- * with the 66 power bits of new_from_config (gates/exponentiation.rs:43-53; CircuitBuilder::exp); `gate_types` is the list
+ * with the 66 power bits of new_from_config (gates/exponentiation.rs:43-53; CircuitBuilder::exp), 9 RandomAccessGate::new_from_config
+ * (gates/random_access.rs:55-72; CircuitBuilder::random_access, Merkle caps) with its index bits (1..6) in `gate_params`; `gate_types` is the list
  * `common_data.gates` (sorted by degree, id) and the group arrays are `selectors_info`
  * (plonky2/src/gates/selectors.rs:17-26). */
 typedef struct gl_circuit_desc {
@@ -82,13 +83,13 @@ typedef struct gl_circuit_desc {
     uint32_t num_public_inputs;
     uint32_t num_gates;                /* <= GL_MAX_GATES                                           */
     uint8_t gate_types[16];
-    uint8_t gate_luts[16];             /* the table (index into the lists below) of a LookupGate / LookupTableGate, else 0 */
+    uint8_t gate_params[16];           /* LookupGate / LookupTableGate: the gate's table (index into the lists below); RandomAccessGate: its index bits; else 0 */
     uint32_t gate_selector_index[16];
     uint32_t gate_group_start[16], gate_group_end[16];
     uint64_t k_is[80];                 /* coset shifts 7^j (field/src/cosets.rs:9-24)               */
     /* ---- lookup argument (up to GL_MAX_LUTS tables; all zero without lookups).  Gate types 6 = LookupGate (40 slots), 7 =
      * LookupTableGate (26 slots) (gates/lookup.rs, gates/lookup_table.rs): one of each PER TABLE in `gate_types`, told apart by
-     * `gate_luts`; `num_constants` counts the lookup selector columns, which sit between the gate selectors and the gates' constants
+     * `gate_params`; `num_constants` counts the lookup selector columns, which sit between the gate selectors and the gates' constants
      * (circuit_builder.rs:991-1004) ---- */
     uint32_t num_lookup_polys;         /* per challenge: 1 RE + ceil(40 / 7) partial SLDC = 7 (circuit_builder.rs:1079-1085)     */
     uint32_t num_lookup_selectors;     /* TransSre, TransLdc, InitSre, LastLdc + one end selector per table = 4 + num_luts     */

@@ -75,6 +75,8 @@ struct CircuitData {
     struct SplitRecipe { Target integer; std::vector<size_t> rows; };
     std::vector<SplitRecipe> split_ops;                 // BaseSumGate rows: sums from the integer, limbs from the sums
     std::vector<size_t> exp_rows;                       // ExponentiationGate rows (one ExponentiationGenerator each)
+    struct RaRecipe { size_t row, copy, bits; };
+    std::vector<RaRecipe> ra_ops;                       // used RandomAccessGate copies (one RandomAccessGenerator each)
     size_t pi_row = 0;
     struct ConstantWire { size_t row, wire; u64 value; };
     std::vector<ConstantWire> constant_wires;           // ConstantGenerator outputs: (row, wire column, value), one ConstantGate per two constants
@@ -105,6 +107,10 @@ struct CircuitBuilder {
     size_t add_gate(GateType t, u64 c0 = 0, u64 c1 = 0, size_t lut = 0) {        // circuit_builder.rs:353-388
         size_t row = gate_instances.size();
         if (t == GATE_CONSTANT) for (size_t i = 0; i < config.num_constants; i++) constant_generators.push_back({row, i, i});
+        if (t == GATE_RANDOM_ACCESS) {                            // extra_constant_wires (random_access.rs:290-294; circuit_builder.rs:364-372)
+            const RandomAccess ra(lut);
+            for (size_t i = 0; i < ra.num_extra_constants; i++) constant_generators.push_back({row, i, ra.wire_extra_constant(i)});
+        }
         gate_instances.push_back({t, {c0, c1}, lut});
         return row;
     }
@@ -192,7 +198,7 @@ struct CircuitBuilder {
         auto it = gate_slots.find(key);
         size_t row, slot;
         if (it != gate_slots.end()) { row = it->second.first; slot = it->second.second; }
-        else { row = add_gate(t, 0, 0, (t == GATE_LOOKUP || t == GATE_LOOKUP_TABLE) ? (size_t)param : 0); slot = 0; }
+        else { row = add_gate(t, 0, 0, (t == GATE_LOOKUP || t == GATE_LOOKUP_TABLE || t == GATE_RANDOM_ACCESS) ? (size_t)param : 0); slot = 0; }
         if (slot == num_ops - 1) gate_slots.erase(key); else gate_slots[key] = {row, slot + 1};
         return {row, slot};
     }
@@ -240,6 +246,32 @@ struct CircuitBuilder {
         return bits;
     }
     void range_check(Target x, size_t n_log) { (void)split_le(x, n_log); }
+
+    // random_access (gadgets/random_access.rs:14-47): one copy of a RandomAccessGate(bits = log2 |v|); its RandomAccessGenerator
+    // (random_access.rs:335-390) sets the claimed element and the index bits
+    struct RaOp { size_t row, copy, bits; };
+    std::vector<RaOp> ra_ops;
+    Target random_access(Target access_index, const std::vector<Target>& v) {
+        if (v.size() == 1) return v[0];
+        size_t bits = 0; while ((size_t(1) << bits) < v.size()) bits++;
+        assert((size_t(1) << bits) == v.size() && bits <= 6);
+        const RandomAccess ra(bits);
+        Target claimed = add_virtual_target();
+        auto rs = find_slot(GATE_RANDOM_ACCESS, (u64)bits, ra.num_copies);
+        for (size_t i = 0; i < v.size(); i++) connect(v[i], Target::wire(rs.first, ra.wire_list_item(i, rs.second)));
+        connect(access_index, Target::wire(rs.first, ra.wire_access_index(rs.second)));
+        connect(claimed, Target::wire(rs.first, ra.wire_claimed_element(rs.second)));
+        ra_ops.push_back({rs.first, rs.second, bits});
+        return claimed;
+    }
+    // le_sum (gadgets/split_base.rs:37-80) for the bit counts whose arithmetic form is the cheaper one (num_bits - 1 <= 20 operations)
+    Target le_sum(const std::vector<Target>& bits) {
+        if (bits.empty()) return zero();
+        assert(bits.size() - 1 <= 20);
+        Target two = constant(2), sum = bits.back();
+        for (size_t i = bits.size() - 1; i-- > 0;) sum = arithmetic(1, 1, two, sum, bits[i]);      // mul_add(two, sum, bit)
+        return sum;
+    }
 
     // exp_from_bits / exp (gadgets/arithmetic.rs:240-272): ONE ExponentiationGate row of 66 power bits, the bits beyond the exponent's
     // tied to _false(); the gate's ExponentiationGenerator (exponentiation.rs:233-280) fills the intermediate values and the output
@@ -352,26 +384,26 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
         return t + "]";
     };
     for (int g = 0; g < GATE_NUM_TYPES; g++)
-        for (size_t li = 0; li < std::max<size_t>(b.luts.size(), 1); li++) {
-            const bool per_table = g == GATE_LOOKUP || g == GATE_LOOKUP_TABLE;
+        for (size_t li = 0; li < 8; li++) {                       // the parameter: a table index, or the bits of a RandomAccessGate
+            const bool per_table = g == GATE_LOOKUP || g == GATE_LOOKUP_TABLE || g == GATE_RANDOM_ACCESS;
             if (!per_table && li) break;
             bool used = false;
             for (auto& gi : b.gate_instances) if (gi.type == (GateType)g && (!per_table || gi.lut == li)) { used = true; break; }
             if (!used) continue;
-            std::string id = gate_id((GateType)g);
+            std::string id = gate_id((GateType)g, li);
             if (g == GATE_LOOKUP) id += lut_text(li).substr(1) + " }";              // gate_id() ends with "lut: ["
             if (g == GATE_LOOKUP_TABLE) id += lut_text(li).substr(1) + ", last_lut_row: " + std::to_string(b.lookup_rows[li].last_lut_gate) + " }";
             kinds.push_back({(GateType)g, li, id});
         }
     std::sort(kinds.begin(), kinds.end(), [](const Kind& x, const Kind& y) {
-        return std::make_pair(gate_degree(x.type), x.id) < std::make_pair(gate_degree(y.type), y.id); });
+        return std::make_pair(gate_degree(x.type, x.lut), x.id) < std::make_pair(gate_degree(y.type, y.lut), y.id); });
     std::vector<GateType> gates;
     SelectorsInfo& si = cm.selectors;
-    for (auto& k : kinds) { gates.push_back(k.type); si.gate_luts.push_back(k.lut); }
+    for (auto& k : kinds) { gates.push_back(k.type); si.gate_params.push_back(k.lut); }
     // selector_polynomials(gates, instances, max_degree = quotient_degree_factor + 1) (selectors.rs:110-185)
     si.gates = gates;
     const size_t max_degree = cm.quotient_degree_factor + 1, num_gates = gates.size();
-    const size_t max_gate_degree = gate_degree(gates.back());
+    const size_t max_gate_degree = gate_degree(gates.back(), si.gate_params.back());
     if (max_gate_degree + num_gates - 1 <= max_degree) {
         si.groups.push_back({0, num_gates});
         si.selector_indices.assign(num_gates, 0);
@@ -380,7 +412,7 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
         size_t start = 0;
         while (start < num_gates) {
             size_t size = 0;
-            while (start + size < num_gates && size + gate_degree(gates[start + size]) < max_degree) size++;
+            while (start + size < num_gates && size + gate_degree(gates[start + size], si.gate_params[start + size]) < max_degree) size++;
             si.groups.push_back({start, start + size});
             start += size;
         }
@@ -412,7 +444,10 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
     }
     // constant_polys (:822-843): max_constants over gate types used
     size_t max_constants = 0;
-    for (auto g : gates) max_constants = std::max<size_t>(max_constants, g == GATE_CONSTANT || g == GATE_ARITHMETIC ? 2 : 0);
+    for (size_t gi = 0; gi < gates.size(); gi++) {
+        const GateType g = gates[gi];
+        max_constants = std::max<size_t>(max_constants, g == GATE_CONSTANT || g == GATE_ARITHMETIC ? 2 : g == GATE_RANDOM_ACCESS ? RandomAccess(si.gate_params[gi]).num_extra_constants : 0);
+    }
     for (size_t c = 0; c < max_constants; c++) {
         std::vector<u64> col(degree);
         for (size_t j = 0; j < degree; j++) col[j] = b.gate_instances[j].constants[c];
@@ -479,6 +514,7 @@ static inline void finish_build(CircuitBuilder& b, CircuitData& cd, unsigned thr
     cd.poseidon_rows = b.poseidon_rows;
     for (auto& so : b.split_ops) cd.split_ops.push_back({so.integer, so.rows});
     cd.exp_rows = b.exp_rows;
+    for (auto& op : b.ra_ops) cd.ra_ops.push_back({op.row, op.copy, op.bits});
     for (auto& lr : b.lookup_rows) cd.lookup_rows.push_back({lr.last_lu_gate, lr.last_lut_gate, lr.first_lut_gate});
     cd.lut_to_lookups = b.lut_to_lookups;
     for (auto& ls : b.lookup_slots) cd.lookup_slots.push_back({ls.row, ls.slot, ls.lut});
@@ -573,6 +609,48 @@ static inline CircuitData build_test_circuit(int kind, size_t param, unsigned th
         b.public_inputs = ins;
         b.public_inputs.insert(b.public_inputs.end(), outs.begin(), outs.end());
         if (kind == 10) b.public_inputs.push_back(b.add_t(outs[0], outs[param]));
+        cd.a_targets = ins;
+    } else if (kind == 16) {
+        // gadgets/random_access.rs:14-47 (its test_random_access_given_len): a list of 2^param targets, `reps` accesses of it at different
+        // indices (reps = 3: several copies of one RandomAccessGate(param)), each result a public input.  Inputs: the list, then the indices.
+        const size_t len = size_t(1) << param, reps = 3;
+        std::vector<Target> v, idx, out;
+        for (size_t i = 0; i < len; i++) v.push_back(b.add_virtual_target());
+        for (size_t r = 0; r < reps; r++) idx.push_back(b.add_virtual_target());
+        for (size_t r = 0; r < reps; r++) out.push_back(b.random_access(idx[r], v));
+        b.public_inputs = idx;
+        b.public_inputs.insert(b.public_inputs.end(), out.begin(), out.end());
+        cd.a_targets = v;
+        cd.a_targets.insert(cd.a_targets.end(), idx.begin(), idx.end());
+    } else if (kind == 17) {
+        // hash/merkle_proofs.rs:93-150 verify_merkle_proof_to_cap with a cap of FOUR digests (cap_height 2), the circuit of its
+        // test_recursive_merkle_proof: `param` index bits, param - 2 siblings, cap_index = le_sum of the top two bits, four random
+        // accesses (RandomAccessGate(2)) into the cap.  Inputs: leaf (5), index, siblings, cap (16); public inputs: cap and index.
+        assert(param >= 2);
+        std::vector<Target> leaf, ins;
+        for (int i = 0; i < 5; i++) leaf.push_back(b.add_virtual_target());
+        Target index = b.add_virtual_target();
+        std::vector<std::array<Target, 4>> sibs(param - 2), cap(4);
+        for (auto& sb : sibs) for (auto& t : sb) t = b.add_virtual_target();
+        for (auto& c : cap) for (auto& t : c) t = b.add_virtual_target();
+        std::vector<Target> bits = b.split_le(index, param);
+        Target z = b.zero();
+        std::array<Target, 4> state = b.hash_or_noop(leaf);
+        for (size_t l = 0; l < sibs.size(); l++) {
+            std::array<Target, 12> in; in.fill(z);
+            for (int i = 0; i < 4; i++) { in[i] = state[i]; in[4 + i] = sibs[l][i]; }
+            auto out = b.permute_swapped(in, bits[l]);
+            for (int i = 0; i < 4; i++) state[i] = out[i];
+        }
+        Target cap_index = b.le_sum(std::vector<Target>(bits.begin() + sibs.size(), bits.end()));
+        for (int i = 0; i < 4; i++) {
+            Target r = b.random_access(cap_index, {cap[0][i], cap[1][i], cap[2][i], cap[3][i]});
+            b.connect(r, state[i]);
+        }
+        ins = leaf; ins.push_back(index);
+        for (auto& sb : sibs) for (auto& t : sb) ins.push_back(t);
+        for (auto& c : cap) for (auto& t : c) { ins.push_back(t); b.public_inputs.push_back(t); }
+        b.public_inputs.push_back(index);
         cd.a_targets = ins;
     } else if (kind == 15) {
         // every supported gate type in one circuit (11 gate types: Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Exponentiation,
@@ -705,6 +783,7 @@ static inline Witness generate_witness(const CircuitData& cd, const std::vector<
                 put(Target::wire(row, 3 * sl + 1), entry < lut.size() ? lut[entry].second : 0);
             }
     }
+    std::vector<char> ra_done(cd.ra_ops.size(), 0);
     std::vector<char> lk_done(cd.lookup_slots.size(), 0);      // LookupGenerator (lookup.rs:151-175): one per slot, needs its looking input
     std::vector<char> arith_done(cd.arith_ops.size(), 0), split_done(cd.split_ops.size(), 0), pos_done(cd.poseidon_rows.size(), 0), exp_done(cd.exp_rows.size(), 0);
     std::vector<u64> rowbuf(135);
@@ -741,6 +820,19 @@ static inline Witness generate_witness(const CircuitData& cd, const std::vector<
             else { while (idx < lut.size() && lut[idx].first != v) idx++; assert(idx < lut.size() && "Incorrect input value provided"); }
             put(Target::wire(ls.row, 2 * ls.slot + 1), lut[idx].second);
             lk_done[k] = 1; progress = true;
+        }
+        for (size_t k = 0; k < cd.ra_ops.size(); k++) {       // RandomAccessGenerator (random_access.rs:335-390)
+            auto& op = cd.ra_ops[k];
+            const RandomAccess ra(op.bits);
+            if (ra_done[k]) continue;
+            bool ready = is_set(Target::wire(op.row, ra.wire_access_index(op.copy)));
+            for (size_t i = 0; i < ra.vec_size && ready; i++) ready = is_set(Target::wire(op.row, ra.wire_list_item(i, op.copy)));
+            if (!ready) continue;
+            const u64 idx = canon(get(Target::wire(op.row, ra.wire_access_index(op.copy))));
+            assert(idx < ra.vec_size && "Access index is larger than the vector size");
+            put(Target::wire(op.row, ra.wire_claimed_element(op.copy)), get(Target::wire(op.row, ra.wire_list_item(idx, op.copy))));
+            for (size_t i = 0; i < ra.bits; i++) put(Target::wire(op.row, ra.wire_bit(i, op.copy)), (idx >> i) & 1);
+            ra_done[k] = 1; progress = true;
         }
         for (size_t k = 0; k < cd.exp_rows.size(); k++) {     // ExponentiationGenerator (exponentiation.rs:233-280)
             const size_t row = cd.exp_rows[k], n = EXP_POWER_BITS;

@@ -31,8 +31,25 @@ template <class K> static inline K ksbox(K x) { K x2 = kmul(x, x), x4 = kmul(x2,
 // (the numbering is the product's gl_circuit_desc.gate_types: 5 = BaseSumGate<2> with the 63 limbs of new_from_config)
 //  6 = LookupGate (40 (input, output) slots), 7 = LookupTableGate (26 (input, output, multiplicity) slots): one of each per lookup table
 //  8 = ExponentiationGate with the 66 power bits of new_from_config (gates/exponentiation.rs:43-53: min(routed - 2, (wires - 2) / 2))
+//  9 = RandomAccessGate::new_from_config(config, bits) (gates/random_access.rs:55-72), one gate type per `bits` (1..6)
 enum GateType { GATE_NOOP = 0, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON, GATE_BASE_SUM, GATE_LOOKUP, GATE_LOOKUP_TABLE, GATE_EXPONENTIATION,
-                GATE_NUM_TYPES };
+                GATE_RANDOM_ACCESS, GATE_NUM_TYPES };
+// RandomAccessGate layout for standard_recursion_config (135 wires, 80 routed, 2 constants): copy c owns wires (2 + 2^bits) c ..: access
+// index, claimed element, the list; then the extra constants; then (unrouted) the index bits of every copy
+struct RandomAccess {
+    size_t bits, vec_size, num_copies, num_extra_constants;
+    explicit RandomAccess(size_t b) : bits(b), vec_size(size_t(1) << b) {
+        num_copies = std::min<size_t>(80 / (2 + vec_size), 135 / (2 + vec_size + bits));
+        num_extra_constants = std::min<size_t>(80 - (2 + vec_size) * num_copies, 2);
+    }
+    size_t wire_access_index(size_t c) const { return (2 + vec_size) * c; }
+    size_t wire_claimed_element(size_t c) const { return (2 + vec_size) * c + 1; }
+    size_t wire_list_item(size_t i, size_t c) const { return (2 + vec_size) * c + 2 + i; }
+    size_t wire_extra_constant(size_t i) const { return (2 + vec_size) * num_copies + i; }
+    size_t num_routed_wires() const { return (2 + vec_size) * num_copies + num_extra_constants; }
+    size_t wire_bit(size_t i, size_t c) const { return num_routed_wires() + c * bits + i; }
+    size_t num_constraints() const { return num_copies * (bits + 2) + num_extra_constants; }
+};
 static const size_t EXP_POWER_BITS = 66;                 // wires: 0 base, 1..66 power bits (little-endian), 67 output, 68..133 intermediate values
 static const size_t LOOKUP_SLOTS = 40, LOOKUP_TABLE_SLOTS = 26;      // gates/lookup.rs:41-44 (routed / 2), gates/lookup_table.rs:47-50 (routed / 3)
 static const size_t NUM_COINS_LOOKUP = 4;                           // circuit_builder.rs:56-58: ChallengeA, ChallengeB, ChallengeAlpha, ChallengeDelta
@@ -41,14 +58,20 @@ enum { LU_SEL_TRANS_SRE = 0, LU_SEL_TRANS_LDC = 1, LU_SEL_INIT_SRE = 2, LU_SEL_L
 static const size_t BASE_SUM_LIMBS = 63;                 // gates/base_sum.rs:31-35: min(log_floor(p - 1, 2) = 63, num_routed_wires - 1 = 79)
 static const size_t UNUSED_SELECTOR = 0xFFFFFFFFull;     // selectors.rs:14
 
-static inline unsigned gate_degree(GateType g) {
+static inline unsigned gate_degree(GateType g, size_t param = 0) {
+    if (g == GATE_RANDOM_ACCESS) return (unsigned)param + 1;      // random_access.rs:281-283
     switch (g) { case GATE_NOOP: return 0; case GATE_CONSTANT: return 1; case GATE_PUBLIC_INPUT: return 1;
                  case GATE_ARITHMETIC: return 3; case GATE_BASE_SUM: return 2 /* base_sum.rs:139-141 */;
                  case GATE_LOOKUP: case GATE_LOOKUP_TABLE: return 0 /* lookup.rs:131-133, lookup_table.rs:150-152 */;
                  case GATE_EXPONENTIATION: return 4 /* exponentiation.rs:186-188 */; default: return 7; }
 }
-static inline std::string gate_id(GateType g) {           // Gate::id(): the sort key next to the degree
+static inline std::string gate_id(GateType g, size_t param = 0) {           // Gate::id(): the sort key next to the degree
     switch (g) {
+        case GATE_RANDOM_ACCESS: {         // format!("{self:?}<D={D}>") (random_access.rs:119-121)
+            RandomAccess ra(param);
+            return "RandomAccessGate { bits: " + std::to_string(ra.bits) + ", num_copies: " + std::to_string(ra.num_copies) + ", num_extra_constants: " +
+                   std::to_string(ra.num_extra_constants) + ", _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>";
+        }
         case GATE_NOOP: return "NoopGate";
         case GATE_CONSTANT: return "ConstantGate { num_consts: 2 }";
         case GATE_PUBLIC_INPUT: return "PublicInputGate";
@@ -63,7 +86,8 @@ static inline std::string gate_id(GateType g) {           // Gate::id(): the sor
         default: return "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>";
     }
 }
-static inline size_t gate_num_constraints(GateType g) {
+static inline size_t gate_num_constraints(GateType g, size_t param = 0) {
+    if (g == GATE_RANDOM_ACCESS) return RandomAccess(param).num_constraints();      // random_access.rs:285-288
     switch (g) { case GATE_NOOP: return 0; case GATE_CONSTANT: return 2; case GATE_PUBLIC_INPUT: return 4;
                  case GATE_ARITHMETIC: return 20; case GATE_BASE_SUM: return 1 + BASE_SUM_LIMBS /* base_sum.rs:144-146 */;
                  case GATE_LOOKUP: case GATE_LOOKUP_TABLE: return 0;          // "No main trace constraints for lookups" (lookup.rs:72-75)
@@ -136,6 +160,26 @@ static inline void eval_base_sum(const K* w, K* out) {                          
     for (size_t i = 0; i < BASE_SUM_LIMBS; i++) out[1 + i] = kmul(w[1 + i], ksub(w[1 + i], kconst<K>(1)));      // (limb - 0)(limb - 1)
 }
 template <class K>
+static inline void eval_random_access(size_t bits, const K* consts, const K* w, K* out) {      // random_access.rs:139-184
+    const RandomAccess ra(bits);
+    size_t c = 0;
+    for (size_t copy = 0; copy < ra.num_copies; copy++) {
+        std::vector<K> items(ra.vec_size);
+        for (size_t i = 0; i < ra.vec_size; i++) items[i] = w[ra.wire_list_item(i, copy)];
+        for (size_t i = 0; i < bits; i++) { const K b = w[ra.wire_bit(i, copy)]; out[c++] = kmul(b, ksub(b, kconst<K>(1))); }
+        K rec = kconst<K>(0);
+        for (size_t i = bits; i-- > 0;) rec = kadd(kadd(rec, rec), w[ra.wire_bit(i, copy)]);
+        out[c++] = ksub(rec, w[ra.wire_access_index(copy)]);
+        for (size_t i = 0; i < bits; i++) {            // fold the list: the left or right item of each pair by bit i
+            const K b = w[ra.wire_bit(i, copy)];
+            for (size_t j = 0; 2 * j + 1 < items.size(); j++) items[j] = kadd(items[2 * j], kmul(b, ksub(items[2 * j + 1], items[2 * j])));
+            items.resize(items.size() / 2);
+        }
+        out[c++] = ksub(items[0], w[ra.wire_claimed_element(copy)]);
+    }
+    for (size_t i = 0; i < ra.num_extra_constants; i++) out[c++] = ksub(consts[i], w[ra.wire_extra_constant(i)]);
+}
+template <class K>
 static inline void eval_exponentiation(const K* w, K* out) {                   // exponentiation.rs:88-124: square-and-multiply, bits big-endian
     const size_t n = EXP_POWER_BITS;
     const K base = w[0], one = kconst<K>(1);
@@ -190,13 +234,13 @@ static inline void eval_poseidon(const K* w, K* out) {                          
 // Selector bookkeeping (selectors.rs:110-185)
 struct SelectorsInfo {
     std::vector<GateType> gates;                 // sorted by (degree, id): circuit_builder.rs:984-986
-    std::vector<size_t> gate_luts;               // per gate: the lookup table of a LookupGate / LookupTableGate (else 0)
+    std::vector<size_t> gate_params;               // per gate: the lookup table of a LookupGate / LookupTableGate, the bits of a RandomAccessGate (else 0)
     std::vector<size_t> selector_indices;        // per gate: which selector polynomial
     std::vector<std::pair<size_t, size_t>> groups;   // [start, end) ranges of gate indices
     size_t num_selectors() const { return groups.size(); }
     size_t num_lookup_selectors = 0;             // lookup selector columns between the gate selectors and the gates' constants
     size_t gate_index(GateType g, size_t lut = 0) const {
-        for (size_t i = 0; i < gates.size(); i++) if (gates[i] == g && (gate_luts.empty() || gate_luts[i] == lut)) return i;
+        for (size_t i = 0; i < gates.size(); i++) if (gates[i] == g && (gate_params.empty() || gate_params[i] == lut)) return i;
         assert(false); return 0;
     }
 };
@@ -221,8 +265,10 @@ static inline void evaluate_gate_constraints(const SelectorsInfo& si, size_t num
     for (size_t gi = 0; gi < si.gates.size(); gi++) {
         const size_t sel = si.selector_indices[gi];
         K filter = compute_filter<K>(gi, si.groups[sel], local_constants[sel], nsel > 1);
-        size_t nc = gate_num_constraints(si.gates[gi]);
+        const size_t param = si.gate_params.empty() ? 0 : si.gate_params[gi];
+        size_t nc = gate_num_constraints(si.gates[gi], param);
         switch (si.gates[gi]) {
+            case GATE_RANDOM_ACCESS: eval_random_access<K>(param, gc, wires, tmp); break;
             case GATE_NOOP: case GATE_LOOKUP: case GATE_LOOKUP_TABLE: break;
             case GATE_CONSTANT: eval_constant<K>(gc, wires, tmp); break;
             case GATE_PUBLIC_INPUT: eval_public_input<K>(pi_hash, wires, tmp); break;

@@ -285,12 +285,13 @@ static void sink_common(ByteSink& o, const CommonData& cm) {
     o.usize(cm.selectors.gates.size());
     for (size_t gi = 0; gi < cm.selectors.gates.size(); gi++) {
         const GateType g = cm.selectors.gates[gi];
-        const size_t li = cm.selectors.gate_luts.empty() ? 0 : cm.selectors.gate_luts[gi];
+        const size_t li = cm.selectors.gate_params.empty() ? 0 : cm.selectors.gate_params[gi];
         switch (g) {
             case GATE_ARITHMETIC: o.word32(0); o.usize(c.num_routed_wires / 4); break;     // ArithmeticGate::new_from_config: num_ops = routed / 4
             case GATE_CONSTANT: o.word32(3); o.usize(c.num_constants); break;
             case GATE_NOOP: o.word32(9); break;
             case GATE_POSEIDON: o.word32(11); break;
+            case GATE_RANDOM_ACCESS: { RandomAccess ra(li); o.word32(13); o.usize(ra.bits); o.usize(ra.num_copies); o.usize(ra.num_extra_constants); break; }   // random_access.rs:123-128
             case GATE_EXPONENTIATION: o.word32(5); o.usize(EXP_POWER_BITS); break;        // write_usize(num_power_bits) (exponentiation.rs:79-81)
             case GATE_BASE_SUM: o.word32(2); o.usize(BASE_SUM_LIMBS); break;              // BaseSumGate<2>: write_usize(num_limbs) (base_sum.rs:53-55)
             case GATE_LOOKUP: o.word32(6); o.usize(LOOKUP_SLOTS); sink_lut(o, cm.luts[li]); break;                    // lookup.rs:59-62
@@ -333,9 +334,9 @@ void orc_circuit_info(const void* c, u64* out) {
     memcpy(out, v, sizeof v);
 }
 // lookup data of a circuit: out3 = [num_lookup_polys, num_lookup_selectors, num_luts]; per table t: rows[4 t ..] = [last_lu_row, last_lut_row,
-// first_lut_row, entries]; lut (may be null) receives the (input, output) pairs of all tables, one after the other; gate_luts (may be null):
+// first_lut_row, entries]; lut (may be null) receives the (input, output) pairs of all tables, one after the other; gate_params (may be null):
 // per gate of the sorted gate list, the table of a LookupGate / LookupTableGate (else 0)
-void orc_circuit_lookup_info(const void* c, u64* out3, u64* rows, uint16_t* lut, uint8_t* gate_luts) {
+void orc_circuit_lookup_info(const void* c, u64* out3, u64* rows, uint16_t* lut, uint8_t* gate_params) {
     const CircuitData* cd = (const CircuitData*)c;
     const CommonData& cm = cd->common;
     out3[0] = cm.num_lookup_polys; out3[1] = cm.num_lookup_selectors; out3[2] = cm.luts.size();
@@ -347,7 +348,7 @@ void orc_circuit_lookup_info(const void* c, u64* out3, u64* rows, uint16_t* lut,
         rows[4 * t + 3] = cm.luts[t].size();
         if (lut) for (auto& e : cm.luts[t]) { lut[2 * off] = e.first; lut[2 * off + 1] = e.second; off++; }
     }
-    if (gate_luts) for (size_t i = 0; i < cm.selectors.gates.size(); i++) gate_luts[i] = (uint8_t)(cm.selectors.gate_luts.empty() ? 0 : cm.selectors.gate_luts[i]);
+    if (gate_params) for (size_t i = 0; i < cm.selectors.gates.size(); i++) gate_params[i] = (uint8_t)(cm.selectors.gate_params.empty() ? 0 : cm.selectors.gate_params[i]);
 }
 void orc_circuit_digest(const void* c, u64* out4) { for (int i = 0; i < 4; i++) out4[i] = canon(((const CircuitData*)c)->circuit_digest.e[i]); }
 void orc_circuit_cs_cap(const void* c, u64* out) { write_digests(((const CircuitData*)c)->constants_sigmas_commitment.tree.cap(), out); }

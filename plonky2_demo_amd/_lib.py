@@ -151,7 +151,7 @@ class CircuitDesc(ctypes.Structure):
         ("num_selectors", c_u32), ("num_challenges", c_u32), ("quotient_degree_factor", c_u32),
         ("rate_bits", c_u32), ("cap_height", c_u32), ("proof_of_work_bits", c_u32), ("num_query_rounds", c_u32),
         ("num_fri_rounds", c_u32), ("fri_arity_bits", c_u32 * 8), ("num_public_inputs", c_u32), ("num_gates", c_u32),
-        ("gate_types", ctypes.c_uint8 * 16), ("gate_luts", ctypes.c_uint8 * 16), ("gate_selector_index", c_u32 * 16),
+        ("gate_types", ctypes.c_uint8 * 16), ("gate_params", ctypes.c_uint8 * 16), ("gate_selector_index", c_u32 * 16),
         ("gate_group_start", c_u32 * 16), ("gate_group_end", c_u32 * 16), ("k_is", c_u64 * 80),
         ("num_lookup_polys", c_u32), ("num_lookup_selectors", c_u32), ("num_luts", c_u32),
         ("last_lu_row", c_u32 * 4), ("last_lut_row", c_u32 * 4), ("first_lut_row", c_u32 * 4), ("lut_len", c_u32 * 4),

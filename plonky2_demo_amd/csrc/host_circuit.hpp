@@ -27,7 +27,24 @@ inline gl_t root_of_unity(unsigned lg) { gl_t r = POW2_GEN; for (unsigned i = lg
 
 // gate type codes shared with the device kernels (order = the reference's sort by (degree, id))
 enum { G_NOOP = 0, G_CONSTANT = 1, G_PUBLIC_INPUT = 2, G_ARITHMETIC = 3, G_POSEIDON = 4, G_BASE_SUM = 5, G_LOOKUP = 6, G_LOOKUP_TABLE = 7, G_EXPONENTIATION = 8,
-       G_LAST = G_EXPONENTIATION };
+       G_RANDOM_ACCESS = 9, G_LAST = G_RANDOM_ACCESS };
+// RandomAccessGate::new_from_config(standard_recursion_config, bits) (gates/random_access.rs:55-110), bits = gate_params[g] in 1..6: copy c
+// owns wires (2 + 2^bits) c ..: access index, claimed element, the list; then the extra constants; then (unrouted) every copy's index bits
+struct RandomAccessLayout {
+    uint32_t bits, vec_size, num_copies, num_extra_constants;
+    GL_HD explicit RandomAccessLayout(uint32_t b) : bits(b), vec_size(1u << b) {
+        const uint32_t by_routed = 80u / (2u + vec_size), by_wires = 135u / (2u + vec_size + bits);
+        num_copies = by_routed < by_wires ? by_routed : by_wires;
+        const uint32_t left = 80u - (2u + vec_size) * num_copies;
+        num_extra_constants = left < 2u ? left : 2u;
+    }
+    GL_HD uint32_t wire_access_index(uint32_t c) const { return (2u + vec_size) * c; }
+    GL_HD uint32_t wire_claimed_element(uint32_t c) const { return (2u + vec_size) * c + 1u; }
+    GL_HD uint32_t wire_list_item(uint32_t i, uint32_t c) const { return (2u + vec_size) * c + 2u + i; }
+    GL_HD uint32_t wire_extra_constant(uint32_t i) const { return (2u + vec_size) * num_copies + i; }
+    GL_HD uint32_t wire_bit(uint32_t i, uint32_t c) const { return (2u + vec_size) * num_copies + num_extra_constants + c * bits + i; }
+    GL_HD uint32_t num_constraints() const { return num_copies * (bits + 2u) + num_extra_constants; }      // random_access.rs:285-288
+};
 // ExponentiationGate::new_from_config (gates/exponentiation.rs:43-53): min(routed - 2, (wires - 2) / 2) = 66 power bits; wires: 0 base,
 // 1..66 power bits (little-endian), 67 output, 68..133 intermediate values; 67 constraints of degree 4
 enum { EXP_POWER_BITS = 66 };
@@ -40,13 +57,21 @@ static const uint64_t UNUSED_SELECTOR = 0xFFFFFFFFull;        // gates/selectors
 // ---- lookup tables of a description: `lut` holds the tables one after the other ----
 inline uint32_t lut_offset(const gl_circuit_desc& d, unsigned t) { uint32_t o = 0; for (unsigned i = 0; i < t && i < GL_MAX_LUTS; i++) o += d.lut_len[i]; return o; }
 inline uint32_t lut_rows(const gl_circuit_desc& d, unsigned t) { return (d.lut_len[t] + LOOKUP_TABLE_SLOTS - 1) / LOOKUP_TABLE_SLOTS; }
+// gate_params of the gates that are not lookup gates: 1..6 bits for a RandomAccessGate, 0 otherwise; nullptr = fine
+inline const char* gate_params_error(const gl_circuit_desc& d) {
+    for (unsigned g = 0; g < d.num_gates && g < GL_MAX_GATES; g++) {
+        if (d.gate_types[g] == G_RANDOM_ACCESS) { if (d.gate_params[g] < 1 || d.gate_params[g] > 6) return "RandomAccessGate: gate_params must hold 1..6 bits"; }
+        else if (d.gate_types[g] != G_LOOKUP && d.gate_types[g] != G_LOOKUP_TABLE && d.gate_params[g] != 0) return "bad gate_params";
+    }
+    return nullptr;
+}
 // the counts every consumer of a description relies on before it indexes lut / lut_len / the per-table rows; nullptr = fine
 inline const char* lookup_shape_error(const gl_circuit_desc& d) {
     if (d.num_luts == 0) {
         if (d.num_lookup_polys || d.num_lookup_selectors) return "lookup polynomials / selectors without a lookup table";
         for (unsigned g = 0; g < d.num_gates && g < GL_MAX_GATES; g++)
             if (d.gate_types[g] == G_LOOKUP || d.gate_types[g] == G_LOOKUP_TABLE) return "lookup gates without a lookup table";
-        return nullptr;
+        return gate_params_error(d);
     }
     if (d.num_luts > GL_MAX_LUTS) return "more than GL_MAX_LUTS lookup tables";
     if (d.num_lookup_polys != 7 || d.num_lookup_selectors != LU_SEL_START_END + d.num_luts)
@@ -58,8 +83,8 @@ inline const char* lookup_shape_error(const gl_circuit_desc& d) {
     }
     if (total > GL_MAX_LUT_ENTRIES) return "the lookup tables together exceed GL_MAX_LUT_ENTRIES entries";
     for (unsigned g = 0; g < d.num_gates && g < GL_MAX_GATES; g++)
-        if ((d.gate_types[g] == G_LOOKUP || d.gate_types[g] == G_LOOKUP_TABLE) ? d.gate_luts[g] >= d.num_luts : d.gate_luts[g] != 0) return "bad gate_luts";
-    return nullptr;
+        if ((d.gate_types[g] == G_LOOKUP || d.gate_types[g] == G_LOOKUP_TABLE) ? d.gate_params[g] >= d.num_luts : (d.gate_types[g] != G_RANDOM_ACCESS && d.gate_params[g] != 0)) return "bad gate_params";
+    return gate_params_error(d);
 }
 // get_lut_poly(common_data, t, deltas, 26 * rows).eval(delta) (vanishing_poly.rs:31-49): the table's combos inp + b out, zero-padded to
 // whole LookupTableGate rows and REVERSED, as coefficients of a polynomial at the delta challenge (Horner from combo_0)

@@ -127,7 +127,7 @@ static int validate_desc(const gl_circuit_desc& d) {
     for (unsigned r = 0; r < d.num_fri_rounds; r++) { GL_REQUIRE(d.fri_arity_bits[r] == 4, GL_ERR_UNSUPPORTED, "FRI arity must be 16"); tot += 4; }
     GL_REQUIRE(tot <= d.degree_bits && d.degree_bits + d.rate_bits >= tot + d.cap_height, GL_ERR_ARG, "FRI total reduction arity is too large");   // circuit_builder.rs:977-980
     for (unsigned g = 0; g < d.num_gates; g++) {
-        GL_REQUIRE(d.gate_types[g] <= glhost::G_LAST, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable, Exponentiation}");
+        GL_REQUIRE(d.gate_types[g] <= glhost::G_LAST, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable, Exponentiation, RandomAccess}");
         GL_REQUIRE(d.gate_selector_index[g] < d.num_selectors && d.gate_group_start[g] <= g && g < d.gate_group_end[g] && d.gate_group_end[g] <= d.num_gates, GL_ERR_ARG, "bad selector group");
     }
     return GL_OK;
@@ -493,12 +493,15 @@ static int quotient_chunks(gl_ctx* ctx, const gl_circuit* cir, const gl_batch* w
             for (unsigned t = 0; t < d.num_luts; t++)
                 q.lut_poly_at_delta[c][t] = glhost::lut_poly_at_delta(d, t, q.deltas[4 * c + glhost::LU_CH_B], q.deltas[4 * c + glhost::LU_CH_DELTA]);
     }
-    for (unsigned g = 0; g < d.num_gates; g++) { q.gate_types[g] = d.gate_types[g]; q.gate_sel[g] = d.gate_selector_index[g]; q.group_start[g] = d.gate_group_start[g]; q.group_end[g] = d.gate_group_end[g]; }
+    for (unsigned g = 0; g < d.num_gates; g++) { q.gate_types[g] = d.gate_types[g]; q.gate_params[g] = d.gate_params[g]; q.gate_sel[g] = d.gate_selector_index[g]; q.group_start[g] = d.gate_group_start[g]; q.group_end[g] = d.gate_group_end[g]; }
     ctx->timing_begin("compute quotient polys");
     hipLaunchKernelGGL(k_quotient<false>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
     bool has_poseidon_gate = false;
     for (unsigned g = 0; g < d.num_gates; g++) has_poseidon_gate |= d.gate_types[g] == 4;
     if (has_poseidon_gate) hipLaunchKernelGGL(k_quotient<true>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
+    bool has_random_access_gate = false;
+    for (unsigned g = 0; g < d.num_gates; g++) has_random_access_gate |= d.gate_types[g] == glhost::G_RANDOM_ACCESS;
+    if (has_random_access_gate) hipLaunchKernelGGL(k_quotient_random_access, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
     if (d.num_lookup_polys) hipLaunchKernelGGL(k_quotient_lookup, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, q);
     ctx->timing_end();
     GL_CHECK_HIP(hipGetLastError());

@@ -167,7 +167,7 @@ struct GlQuotParams {
     const gl_t* l0_coset;           // L_0 on the coset: l0_coset[i] = Z_H(x_i) / (n (x_i - 1)), x_i = 7 w_N^i (built with the circuit)
     uint32_t lgN, num_constants, num_selectors, num_gates, next_step;
     uint32_t k_is_powers_of_7;
-    uint8_t gate_types[GL_MAX_GATES];
+    uint8_t gate_types[GL_MAX_GATES], gate_params[GL_MAX_GATES];
     uint32_t gate_sel[GL_MAX_GATES], group_start[GL_MAX_GATES], group_end[GL_MAX_GATES];
     // lookup argument (zero without lookups): the lookup selector columns sit between the gate selectors and the gates' constants, the
     // lookup polynomials behind Z and the partial products, their 2 x (16 + num_luts) terms between the partial-product checks and the
@@ -481,6 +481,76 @@ __global__ __launch_bounds__(256) void k_quotient_lookup(GlQuotParams p) {
     const gl_t zi = p.zh_inv[i & 7];
     p.out[i] = gl_canon(gl_add(p.out[i], gl_mul(tot[0], zi)));
     p.out[N + i] = gl_canon(gl_add(p.out[N + i], gl_mul(tot[1], zi)));
+}
+
+// ---- RandomAccessGate (gates/random_access.rs:139-184) ------------------------------------------------------------------------------
+// A launch of its own, made only for circuits that have the gate (like the PoseidonGate and lookup launches): its list folding would
+// otherwise set the register budget of k_quotient<false> for every circuit.  Adds sum_g filter_g * sum_j alpha^(T0 + j) c_{g,j} / Z_H(x)
+// of the RandomAccessGates to both outputs.  BITS = gate_params[g]; per copy: BITS boolean checks, the index reconstruction, the folded
+// list against the claimed element; then the extra constants.
+template <int BITS>
+__device__ __forceinline__ void glq_random_access_gate(const gl_t* w, const gl_t* gc, size_t N, GlAlphaAcc& acc, uint32_t T0) {
+    const glhost::RandomAccessLayout ra(BITS);
+    constexpr int VEC = 1 << BITS;
+    uint32_t t = T0;
+#pragma unroll 1
+    for (uint32_t copy = 0; copy < ra.num_copies; copy++) {
+        gl_t b[BITS];
+#pragma unroll
+        for (int k = 0; k < BITS; k++) { b[k] = w[(size_t)ra.wire_bit(k, copy) * N]; acc.add(t++, glx_mul<true>(b[k], glx_sub_cc(b[k], 1))); }
+        gl_t rec = 0;
+#pragma unroll
+        for (int k = BITS - 1; k >= 0; k--) rec = glx_add_cc(glx_add_cc(rec, rec), b[k]);
+        acc.add(t++, glx_sub_cc(rec, w[(size_t)ra.wire_access_index(copy) * N]));
+        // fold the list pairwise by bit 0, then bit 1, ...: x + b (y - x).  The first fold reads the 2^BITS items from memory.
+        gl_t items[VEC / 2];
+#pragma unroll
+        for (int j = 0; j < VEC / 2; j++) {
+            const gl_t x = w[(size_t)ra.wire_list_item(2 * j, copy) * N], y = w[(size_t)ra.wire_list_item(2 * j + 1, copy) * N];
+            items[j] = glx_add_cc(x, glx_mul<true>(b[0], glx_sub_cc(y, x)));
+        }
+#pragma unroll
+        for (int k = 1; k < BITS; k++) {
+#pragma unroll
+            for (int j = 0; j < (VEC >> (k + 1)); j++) items[j] = glx_add_cc(items[2 * j], glx_mul<true>(b[k], glx_sub_cc(items[2 * j + 1], items[2 * j])));
+        }
+        acc.add(t++, glx_sub_cc(items[0], w[(size_t)ra.wire_claimed_element(copy) * N]));
+    }
+    for (uint32_t k = 0; k < ra.num_extra_constants; k++) acc.add(t++, glx_sub_cc(gc[(size_t)k * N], w[(size_t)ra.wire_extra_constant(k) * N]));
+}
+__global__ __launch_bounds__(256) void k_quotient_random_access(GlQuotParams p) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t N = size_t(1) << p.lgN;
+    if (i >= N) return;
+    const gl_t* w = p.wires + i;
+    const gl_t* cs = p.cs + i;
+    const gl_t* gc = cs + (size_t)(p.num_selectors + p.num_lookup_selectors) * N;
+    gl_t tot0 = 0, tot1 = 0;
+#pragma unroll 1
+    for (uint32_t g = 0; g < p.num_gates; g++) {
+        if (p.gate_types[g] != 9) continue;
+        const gl_t sel = cs[(size_t)p.gate_sel[g] * N];
+        gl_t filter = 1;                                            // gate.rs:277-284
+        for (uint32_t k = p.group_start[g]; k < p.group_end[g]; k++) if (k != g) filter = glx_mul<true>(filter, glx_sub_cc((gl_t)k, sel));
+        if (p.num_selectors > 1) filter = glx_mul<true>(filter, glx_sub_cc((gl_t)0xFFFFFFFFull, sel));
+        GlAlphaAcc acc; acc.start(p.alpha_pows);
+        switch (p.gate_params[g]) {
+            case 1: glq_random_access_gate<1>(w, gc, N, acc, p.gate_term0); break;
+            case 2: glq_random_access_gate<2>(w, gc, N, acc, p.gate_term0); break;
+            case 3: glq_random_access_gate<3>(w, gc, N, acc, p.gate_term0); break;
+            case 4: glq_random_access_gate<4>(w, gc, N, acc, p.gate_term0); break;
+            case 5: glq_random_access_gate<5>(w, gc, N, acc, p.gate_term0); break;
+            default: glq_random_access_gate<6>(w, gc, N, acc, p.gate_term0); break;
+        }
+        gl_t fs0, fs1, unused;
+        glx_mul3<true>(filter, acc.sum(0), filter, acc.sum(1), 0, 0, fs0, fs1, unused);
+        tot0 = glx_add_cc(tot0, fs0); tot1 = glx_add_cc(tot1, fs1);
+    }
+    const gl_t zi = p.zh_inv[i & 7];
+    gl_t o0, o1, unused;
+    glx_mul3<true>(tot0, zi, tot1, zi, 0, 0, o0, o1, unused);
+    p.out[i] = glx_add_cc(p.out[i], o0);
+    p.out[N + i] = glx_add_cc(p.out[N + i], o1);
 }
 
 // compute_lookup_polys (plonk/prover.rs:425-541).  Step 1: 1 / (alpha - (inp + a out)) for every slot of every lookup row, in parallel:

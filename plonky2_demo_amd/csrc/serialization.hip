@@ -18,7 +18,7 @@
 
 namespace {
 // position of each gate type in DefaultGateSerializer's list (gate_serialization.rs:89-107)
-const uint32_t TAG_ARITHMETIC = 0, TAG_BASE_SUM_2 = 2, TAG_CONSTANT = 3, TAG_EXPONENTIATION = 5, TAG_LOOKUP = 6, TAG_LOOKUP_TABLE = 7, TAG_NOOP = 9, TAG_POSEIDON = 11, TAG_PUBLIC_INPUT = 12;
+const uint32_t TAG_ARITHMETIC = 0, TAG_BASE_SUM_2 = 2, TAG_CONSTANT = 3, TAG_EXPONENTIATION = 5, TAG_LOOKUP = 6, TAG_LOOKUP_TABLE = 7, TAG_NOOP = 9, TAG_POSEIDON = 11, TAG_PUBLIC_INPUT = 12, TAG_RANDOM_ACCESS = 13;
 const uint64_t LOOKUP_SLOTS = 40, LOOKUP_TABLE_SLOTS = 26;     // gates/lookup.rs:41-44, gates/lookup_table.rs:47-50
 const uint64_t BASE_SUM_LIMBS = 63;     // BaseSumGate::<2>::new_from_config under standard_recursion_config (gates/base_sum.rs:31-35)
 // standard_recursion_config (plonk/circuit_data.rs:72-90)
@@ -51,9 +51,10 @@ struct Reader {
 };
 
 uint32_t gate_tag(uint8_t type) {
-    switch (type) { case 0: return TAG_NOOP; case 1: return TAG_CONSTANT; case 2: return TAG_PUBLIC_INPUT; case 3: return TAG_ARITHMETIC; case 5: return TAG_BASE_SUM_2; case 6: return TAG_LOOKUP; case 7: return TAG_LOOKUP_TABLE; case 8: return TAG_EXPONENTIATION; default: return TAG_POSEIDON; }
+    switch (type) { case 0: return TAG_NOOP; case 1: return TAG_CONSTANT; case 2: return TAG_PUBLIC_INPUT; case 3: return TAG_ARITHMETIC; case 5: return TAG_BASE_SUM_2; case 6: return TAG_LOOKUP; case 7: return TAG_LOOKUP_TABLE; case 8: return TAG_EXPONENTIATION; case 9: return TAG_RANDOM_ACCESS; default: return TAG_POSEIDON; }
 }
-uint64_t gate_constraints(uint8_t type, const gl_circuit_desc& d) {
+uint64_t gate_constraints(uint8_t type, uint8_t param, const gl_circuit_desc& d) {
+    if (type == 9) return glhost::RandomAccessLayout(param).num_constraints();
     switch (type) { case 0: case 6: case 7: return 0; case 1: return d.num_constants - d.num_selectors - d.num_lookup_selectors; case 2: return 4; case 3: return d.num_routed_wires / 4; case 5: return 1 + BASE_SUM_LIMBS /* gates/base_sum.rs:144-146 */; case 8: return glhost::EXP_POWER_BITS + 1 /* gates/exponentiation.rs:190-192 */; default: return 123; }   // gates/poseidon.rs:403-409
 }
 void write_fri_config(Writer& w, const gl_circuit_desc& d) {          // mod.rs:1628-1644
@@ -82,7 +83,7 @@ extern "C" int gl_common_data_to_bytes(const gl_circuit_desc* desc, uint8_t* h_o
     // everything the writer indexes or divides by (k_is holds 80 entries)
     GL_REQUIRE(d.num_routed_wires >= 4 && d.num_routed_wires <= 80 && d.quotient_degree_factor >= 1 && d.num_constants >= d.num_selectors, GL_ERR_ARG,
                "bad circuit description: routed wires 4..80, quotient degree factor >= 1, constants >= selectors");
-    for (uint32_t g = 0; g < d.num_gates; g++) GL_REQUIRE(d.gate_types[g] <= glhost::G_LAST, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable, Exponentiation}");
+    for (uint32_t g = 0; g < d.num_gates; g++) GL_REQUIRE(d.gate_types[g] <= glhost::G_LAST, GL_ERR_UNSUPPORTED, "gate type not in {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable, Exponentiation, RandomAccess}");
     { const char* why = glhost::lookup_shape_error(d); GL_REQUIRE(!why, GL_ERR_ARG, why); }
     GL_REQUIRE(d.num_constants >= d.num_selectors + d.num_lookup_selectors, GL_ERR_ARG, "bad lookup description");
     Writer w;
@@ -101,11 +102,12 @@ extern "C" int gl_common_data_to_bytes(const gl_circuit_desc* desc, uint8_t* h_o
         w.u32(gate_tag(d.gate_types[g]));
         if (d.gate_types[g] == 3) w.u64(d.num_routed_wires / 4);                   // ArithmeticGate { num_ops }
         if (d.gate_types[g] == 1) w.u64(d.num_constants - d.num_selectors - d.num_lookup_selectors);      // ConstantGate { num_consts }
-        if (d.gate_types[g] == 6) { w.u64(LOOKUP_SLOTS); w.lut(d, d.gate_luts[g]); }                // LookupGate { num_slots, lut } (gates/lookup.rs:59-62)
-        if (d.gate_types[g] == 7) { w.u64(LOOKUP_TABLE_SLOTS); w.lut(d, d.gate_luts[g]); w.u64(d.last_lut_row[d.gate_luts[g]]); }      // LookupTableGate (gates/lookup_table.rs:70-74)
+        if (d.gate_types[g] == 6) { w.u64(LOOKUP_SLOTS); w.lut(d, d.gate_params[g]); }                // LookupGate { num_slots, lut } (gates/lookup.rs:59-62)
+        if (d.gate_types[g] == 7) { w.u64(LOOKUP_TABLE_SLOTS); w.lut(d, d.gate_params[g]); w.u64(d.last_lut_row[d.gate_params[g]]); }      // LookupTableGate (gates/lookup_table.rs:70-74)
         if (d.gate_types[g] == 5) w.u64(BASE_SUM_LIMBS);                           // BaseSumGate<2> { num_limbs } (gates/base_sum.rs:53-55)
+        if (d.gate_types[g] == 9) { const glhost::RandomAccessLayout ra(d.gate_params[g]); w.u64(ra.bits); w.u64(ra.num_copies); w.u64(ra.num_extra_constants); }      // random_access.rs:123-128
         if (d.gate_types[g] == 8) w.u64(glhost::EXP_POWER_BITS);                   // ExponentiationGate { num_power_bits } (gates/exponentiation.rs:79-81)
-        const uint64_t c = gate_constraints(d.gate_types[g], d);
+        const uint64_t c = gate_constraints(d.gate_types[g], d.gate_params[g], d);
         if (c > max_constraints) max_constraints = c;
     }
     // SelectorsInfo (mod.rs:1700-1713): selector_indices, then the distinct groups in order
@@ -175,6 +177,16 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
             const uint64_t limbs = r.u64();
             GL_REQUIRE(!r.ok || limbs == BASE_SUM_LIMBS, GL_ERR_UNSUPPORTED, "BaseSumGate<2> with a limb count other than new_from_config's 63");
         }
+        else if (tag == TAG_RANDOM_ACCESS) {
+            d.gate_types[g] = 9;
+            const uint64_t bits = r.u64(), copies = r.u64(), extra = r.u64();
+            GL_REQUIRE(!r.ok || (bits >= 1 && bits <= 6), GL_ERR_UNSUPPORTED, "RandomAccessGate: 1..6 index bits");
+            if (r.ok) {
+                const glhost::RandomAccessLayout ra((uint32_t)bits);
+                GL_REQUIRE(copies == ra.num_copies && extra == ra.num_extra_constants, GL_ERR_UNSUPPORTED, "RandomAccessGate with a layout other than new_from_config's");
+                d.gate_params[g] = (uint8_t)bits;
+            }
+        }
         else if (tag == TAG_EXPONENTIATION) {
             d.gate_types[g] = 8;
             const uint64_t bits = r.u64();
@@ -188,7 +200,7 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
             for (uint64_t k = 0; k < 2 * len && r.ok; k++) gate_table[g].push_back(r.u16());
             if (tag == TAG_LOOKUP_TABLE) gate_last_lut_row[g] = r.usize32();
         }
-        else return gl_fail(GL_ERR_UNSUPPORTED, "gate outside {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable, Exponentiation}", __FILE__, __LINE__);
+        else return gl_fail(GL_ERR_UNSUPPORTED, "gate outside {Noop, Constant, PublicInput, Arithmetic, Poseidon, BaseSum<2>, Lookup, LookupTable, Exponentiation, RandomAccess}", __FILE__, __LINE__);
     }
     const uint64_t nsel = r.u64();
     GL_REQUIRE(r.ok && nsel == ngates, GL_ERR_ARG, "selector_indices length differs from the number of gates");
@@ -233,7 +245,7 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
             if (gate_table[g].size() == 2 * (size_t)d.lut_len[t] && std::equal(gate_table[g].begin(), gate_table[g].end(), e)) break;
         }
         GL_REQUIRE(t < nluts, GL_ERR_ARG, "a lookup gate's table is not one of CommonCircuitData's luts");
-        d.gate_luts[g] = (uint8_t)t;
+        d.gate_params[g] = (uint8_t)t;
         if (d.gate_types[g] == 7) {
             // LookupWire is prover data (circuit_data.rs:296-299), not part of these bytes: last_lut_row is the LookupTableGate's field,
             // first_lut_row follows from the table length; last_lu_row is unknown here and left 0 (the verifier does not need it; build()

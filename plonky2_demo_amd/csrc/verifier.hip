@@ -265,6 +265,25 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
                     for (int i = 0; i < glhost::BASE_SUM_LIMBS; i++) tmp[1 + i] = e_mul(wires[1 + i], e_sub(wires[1 + i], e_of(1)));
                     break;
                 }
+                case glhost::G_RANDOM_ACCESS: {                                                                                                         // random_access.rs:139-184
+                    const glhost::RandomAccessLayout ra(d.gate_params[g]);
+                    for (uint32_t copy = 0; copy < ra.num_copies; copy++) {
+                        std::vector<E> items(ra.vec_size);
+                        for (uint32_t i = 0; i < ra.vec_size; i++) items[i] = wires[ra.wire_list_item(i, copy)];
+                        for (uint32_t i = 0; i < ra.bits; i++) { const E b = wires[ra.wire_bit(i, copy)]; tmp[cnt++] = e_mul(b, e_sub(b, e_of(1))); }
+                        E rec = e_of(0);
+                        for (uint32_t i = ra.bits; i-- > 0;) rec = e_add(e_add(rec, rec), wires[ra.wire_bit(i, copy)]);
+                        tmp[cnt++] = e_sub(rec, wires[ra.wire_access_index(copy)]);
+                        for (uint32_t i = 0; i < ra.bits; i++) {                                                                                         // fold the list by bit i
+                            const E b = wires[ra.wire_bit(i, copy)];
+                            for (size_t j = 0; 2 * j + 1 < items.size(); j++) items[j] = e_add(items[2 * j], e_mul(b, e_sub(items[2 * j + 1], items[2 * j])));
+                            items.resize(items.size() / 2);
+                        }
+                        tmp[cnt++] = e_sub(items[0], wires[ra.wire_claimed_element(copy)]);
+                    }
+                    for (uint32_t i = 0; i < ra.num_extra_constants; i++) tmp[cnt++] = e_sub(gate_consts[i], wires[ra.wire_extra_constant(i)]);
+                    break;
+                }
                 case glhost::G_EXPONENTIATION: {                                                                                                        // exponentiation.rs:88-124
                     const int n = glhost::EXP_POWER_BITS;
                     cnt = n + 1;

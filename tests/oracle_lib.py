@@ -304,8 +304,8 @@ class OracleCircuit:
         for j in range(80):
             d.k_is[j] = int(k[j])
         li, rows = np.zeros(3, dtype=np.uint64), np.zeros(4 * 8, dtype=np.uint64)
-        lut, gate_luts = np.zeros(2048, dtype=np.uint16), np.zeros(16, dtype=np.uint8)
-        lib.orc_circuit_lookup_info(self.h, _p(li), _p(rows), lut.ctypes.data_as(ctypes.c_void_p), gate_luts.ctypes.data_as(ctypes.c_void_p))
+        lut, gate_params = np.zeros(2048, dtype=np.uint16), np.zeros(16, dtype=np.uint8)
+        lib.orc_circuit_lookup_info(self.h, _p(li), _p(rows), lut.ctypes.data_as(ctypes.c_void_p), gate_params.ctypes.data_as(ctypes.c_void_p))
         d.num_lookup_polys, d.num_lookup_selectors, d.num_luts = [int(x) for x in li]
         assert d.num_luts <= 4
         for t in range(d.num_luts):
@@ -313,7 +313,7 @@ class OracleCircuit:
         for j in range(2 * sum(d.lut_len[t] for t in range(d.num_luts))):
             d.lut[j] = int(lut[j])
         for g in range(d.num_gates):
-            d.gate_luts[g] = int(gate_luts[g])
+            d.gate_params[g] = int(gate_params[g])
         return d
 
     @property

@@ -882,6 +882,29 @@ def test_range_check_circuits_with_base_sum_gate(gpu, orc, bits, value):
     assert not cd.verify(bytes(bad))[0] and not oc.verify_bytes(bytes(bad), cd.constants_sigmas_cap, cd.circuit_digest)[0]
 
 
+@pytest.mark.parametrize("kind,param", [(16, 1), (16, 2), (16, 3), (16, 4), (16, 5), (16, 6), (17, 2), (17, 5), (17, 10)])
+def test_random_access_gate_circuits(gpu, orc, kind, param):
+    # RandomAccessGate (gates/random_access.rs; gate_params = bits 1..6) behind CircuitBuilder::random_access, and
+    # verify_merkle_proof_to_cap with a cap of four digests (hash/merkle_proofs.rs:93-150): k_quotient_random_access (a launch of its own),
+    # constants hosted in the gate's extra constant wires.  GPU proof bytes == the oracle's.  PARITY UNPINNED against a Rust proof.
+    from test_verifier import cap_proof_circuit_inputs
+    p, ctx = gpu
+    oc = orc.circuit_of_kind(kind, param, threads=8)
+    if kind == 16:
+        v = rand_field(param, (1 << param,))
+        idx = np.array([0, (1 << param) - 1, 5 % (1 << param)], dtype=np.uint64)
+        w = oc.witness(np.concatenate([v, idx]), np.zeros(0, dtype=np.uint64), filler_seed=param)
+        expect = [int(i) for i in idx] + [int(v[int(i)]) for i in idx]
+    else:
+        index = (0x2D5 >> 1) % (1 << param)
+        a, cap4 = cap_proof_circuit_inputs(orc, param, index)
+        w = oc.witness(a, np.zeros(0, dtype=np.uint64), filler_seed=param)
+        expect = [int(x) for x in cap4] + [index]
+    _prove_generic_and_compare(p, oc, w)
+    assert [int(x) for x in w.public_inputs()] == expect
+    assert 9 in list(oc.product_desc().gate_types)[:oc.product_desc().num_gates]
+
+
 @pytest.mark.parametrize("bits,x,y", [(9, 200, 300), (16, 255, 65535), (1, 0, 0)])
 def test_a_circuit_with_every_supported_gate_type(gpu, orc, bits, x, y):
     # 11 gate types in three selector groups (oracle kind 15: two lookup tables, BaseSum<2>, Arithmetic, Exponentiation, Poseidon, ...):

@@ -216,7 +216,7 @@ def test_common_data_writer_validates_its_description():
         with pytest.raises(p.Plonky2Mi355xError):
             api.common_data_to_bytes(d)
     d = copy.copy(hc.desc)
-    d.gate_types[0] = 9                                   # 0..7 are the supported gate types
+    d.gate_types[0] = 10                                  # 0..9 are the supported gate types
     with pytest.raises(p.Plonky2Mi355xError) as e:
         api.common_data_to_bytes(d)
     assert e.value.code == 3
@@ -228,7 +228,7 @@ def test_common_data_writer_validates_its_description():
         with pytest.raises(p.Plonky2Mi355xError):
             api.common_data_to_bytes(d)
     d = copy.copy(hc.desc)
-    d.gate_luts[0] = 1                                    # a table index on a gate that has none
+    d.gate_params[0] = 1                                    # a table index on a gate that has none
     d.num_luts, d.num_lookup_polys, d.num_lookup_selectors, d.lut_len[0] = 1, 7, 5, 4
     with pytest.raises(p.Plonky2Mi355xError):
         api.common_data_to_bytes(d)
@@ -314,6 +314,66 @@ def test_exponentiation_gate_circuits_verify_natively_and_through_the_byte_form(
     with pytest.raises(p.Plonky2Mi355xError) as e:
         api.common_data_from_bytes(bytes(bad))
     assert e.value.code == 3
+
+
+def cap_proof_circuit_inputs(orc, height, index, seed=11):
+    """Inputs of the oracle's Merkle-proof-to-cap circuit (kind 17, cap of four digests): leaf (5), index, siblings, cap (16)."""
+    from oracle_lib import rand_field
+    leaves = rand_field(seed, (1 << height, 5))
+    tree = orc.merkle(leaves, 2)
+    a = np.concatenate([leaves[index], np.array([index], dtype=np.uint64), tree.prove(index).reshape(-1), tree.cap.reshape(-1)])
+    return a, tree.cap.reshape(-1)
+
+
+@pytest.mark.parametrize("kind,param", [(16, 1), (16, 2), (16, 3), (16, 4), (16, 5), (16, 6), (17, 2), (17, 6)])
+def test_random_access_gate_circuits_verify_natively_and_through_the_byte_form(orc, kind, param):
+    # RandomAccessGate::new_from_config(bits) (gate type 9, gate_params = bits in 1..6: 20 / 13 / 8 / 4 / 2 / 1 copies per row, two extra
+    # constant wires for bits 2, 4, 5, 6 -- which then host the circuit's constants instead of a ConstantGate) behind
+    # CircuitBuilder::random_access (gadgets/random_access.rs:14-47), and verify_merkle_proof_to_cap with a cap of four digests
+    # (hash/merkle_proofs.rs:93-150: le_sum of the top index bits, four random accesses): gl_verify accepts the oracle's proofs and agrees
+    # with it on mutations; the circuit data round-trips through the byte form (gate tag 13: bits, num_copies, num_extra_constants)
+    import ctypes
+    import plonky2_demo_amd as p
+    from plonky2_demo_amd import api
+    from plonky2_demo_amd._lib import lib, GL_OK
+    from oracle_lib import rand_field
+    oc = orc.circuit_of_kind(kind, param, threads=4)
+    if kind == 16:
+        v = rand_field(param, (1 << param,))
+        idx = np.array([0, (1 << param) - 1, 5 % (1 << param)], dtype=np.uint64)
+        w = oc.witness(np.concatenate([v, idx]), np.zeros(0, dtype=np.uint64), filler_seed=1)
+        assert [int(x) for x in w.public_inputs()] == [int(i) for i in idx] + [int(v[int(i)]) for i in idx]
+        bits = param
+    else:
+        index = (0x2D5 >> 1) % (1 << param)
+        a, cap4 = cap_proof_circuit_inputs(orc, param, index)
+        w = oc.witness(a, np.zeros(0, dtype=np.uint64), filler_seed=1)
+        assert [int(x) for x in w.public_inputs()] == [int(x) for x in cap4] + [index]
+        bits = 2
+    proof = w.prove(threads=4).to_bytes()
+    desc = oc.product_desc()
+    gates = list(desc.gate_types)[:desc.num_gates]
+    assert gates.count(9) == 1 and desc.gate_params[gates.index(9)] == bits
+    cap, dig = np.ascontiguousarray(oc.constants_sigmas_cap), np.ascontiguousarray(oc.digest)
+    vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+
+    def native(by):
+        buf = np.frombuffer(by, dtype=np.uint8)
+        return lib.gl_verify(ctypes.byref(desc), vp(cap), vp(dig), vp(buf), buf.size) == GL_OK
+    assert native(proof), lib.gl_last_error()
+    common = api.common_data_to_bytes(desc)
+    assert common == oc.data_bytes(0)
+    d2, used = api.common_data_from_bytes(common)
+    assert used == len(common) and bytes(d2) == bytes(desc)
+    rng = np.random.default_rng(param)
+    for _ in range(30):
+        bad = bytearray(proof)
+        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        assert native(bytes(bad)) == oc.verify_bytes(bytes(bad), cap, dig)[0]
+    bad = copy_desc = type(desc).from_buffer_copy(bytes(desc))
+    bad.gate_params[gates.index(9)] = 7
+    with pytest.raises(p.Plonky2Mi355xError):
+        api.common_data_to_bytes(bad)
 
 
 def test_a_circuit_with_every_supported_gate_type_verifies_natively_and_through_the_byte_form(orc):
@@ -433,7 +493,7 @@ def test_lookup_argument_circuits_verify_natively_and_through_the_byte_form(orc,
     assert desc.num_luts == nluts and desc.num_lookup_polys == 7 and desc.num_lookup_selectors == 4 + nluts
     gates = list(desc.gate_types)[:desc.num_gates]
     assert gates.count(6) == nluts and gates.count(7) == nluts
-    assert sorted(desc.gate_luts[g] for g in range(desc.num_gates) if gates[g] == 7) == list(range(nluts))
+    assert sorted(desc.gate_params[g] for g in range(desc.num_gates) if gates[g] == 7) == list(range(nluts))
     cap, dig = np.ascontiguousarray(oc.constants_sigmas_cap), np.ascontiguousarray(oc.digest)
     vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
 
