@@ -77,8 +77,8 @@ static inline std::string gate_id(GateType g, size_t param = 0) {           // G
         case GATE_PUBLIC_INPUT: return "PublicInputGate";
         case GATE_ARITHMETIC: return "ArithmeticGate { num_ops: 20 }";
         case GATE_BASE_SUM: return "BaseSumGate { num_limbs: 63 } + Base: 2";          // base_sum.rs:49-51
-        // format!("{self:?}") of the gate structs (lookup.rs:55-57, lookup_table.rs:66-68); with ONE table the prefixes decide every
-        // comparison against the other gate types of degree 0 ("LookupGate {" < "LookupTableGate {" < "NoopGate")
+        // format!("{self:?}") of the gate structs (lookup.rs:55-57, lookup_table.rs:66-68) up to the table: finish_build() appends the
+        // table's text (and last_lut_row), which orders the gates of several tables ("LookupGate {" < "LookupTableGate {" < "NoopGate")
         case GATE_LOOKUP: return "LookupGate { num_slots: 40, lut: [";
         case GATE_LOOKUP_TABLE: return "LookupTableGate { num_slots: 26, lut: [";
         case GATE_EXPONENTIATION:          // format!("{self:?}<D={D}>") (exponentiation.rs:75-77)
