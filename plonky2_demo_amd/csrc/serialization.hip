@@ -214,13 +214,13 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
         for (uint32_t g = start; g < end; g++) { d.gate_group_start[g] = start; d.gate_group_end[g] = end; }
     }
     d.quotient_degree_factor = r.usize32();
-    (void)r.u64();                                      // num_gate_constraints: implied by the gate list
+    const uint64_t num_gate_constraints = r.u64();      // implied by the gate list: checked below, once the constant columns are known
     d.num_constants = r.usize32();
     d.num_public_inputs = r.usize32();
     const uint64_t nk = r.u64();
     GL_REQUIRE(r.ok && nk == d.num_routed_wires && nk <= 80, GL_ERR_UNSUPPORTED, "k_is: one coset shift per routed wire, at most 80");
     for (uint64_t j = 0; j < nk; j++) d.k_is[j] = r.u64();
-    (void)r.u64();                                      // num_partial_products: implied
+    const uint64_t num_partial_products = r.u64();      // implied: checked below
     const uint64_t nlp = r.u64(), nls = r.u64(), nluts = r.u64();
     GL_REQUIRE(!r.wide, GL_ERR_UNSUPPORTED, "a size field of CommonCircuitData exceeds 32 bits");
     GL_REQUIRE(r.ok, GL_ERR_ARG, "truncated CommonCircuitData");
@@ -258,6 +258,13 @@ extern "C" int gl_common_data_from_bytes(const uint8_t* h_bytes, size_t num_byte
     for (uint64_t t = 0; t < nluts; t++) GL_REQUIRE(has_table_gate[t], GL_ERR_ARG, "a lookup table without its LookupTableGate");
     GL_REQUIRE(max_qdf == d.quotient_degree_factor && cfg_consts + d.num_selectors + d.num_lookup_selectors == d.num_constants, GL_ERR_UNSUPPORTED, "constants / quotient degree layout");
     GL_REQUIRE((!arith_ops || arith_ops == d.num_routed_wires / 4) && (!const_consts || const_consts == cfg_consts), GL_ERR_UNSUPPORTED, "gate parameters");
+    {   // the two redundant fields must say what the rest implies (the writer derives them the same way)
+        uint64_t max_constraints = 0;
+        for (uint32_t g = 0; g < d.num_gates; g++) max_constraints = std::max<uint64_t>(max_constraints, gate_constraints(d.gate_types[g], d.gate_params[g], d));
+        GL_REQUIRE(d.quotient_degree_factor >= 1 && num_gate_constraints == max_constraints &&
+                   num_partial_products == (d.num_routed_wires + d.quotient_degree_factor - 1) / d.quotient_degree_factor - 1, GL_ERR_ARG,
+                   "num_gate_constraints / num_partial_products differ from what the gates and the routed wires imply");
+    }
     *out = d;
     if (consumed) *consumed = r.pos;
     return GL_OK;

@@ -149,6 +149,10 @@ extern "C" int gl_verify(const gl_circuit_desc* desc, const uint64_t* constants_
     GL_REQUIRE(d.num_selectors >= 1 && d.num_constants == d.num_selectors + d.num_lookup_selectors + 2 && d.num_fri_rounds <= 8 &&
                d.degree_bits >= 1 && d.degree_bits + d.rate_bits <= 32 && d.cap_height <= d.degree_bits + d.rate_bits && d.num_query_rounds >= 1,
                GL_ERR_ARG, "gl_verify: bad circuit description");
+    // every count that sizes an allocation below is bounded by what a proof of num_bytes can hold (a description is caller-filled, but a
+    // wrong one must be refused, not turned into a 2^40-byte allocation: tools/sanitizer/data_fuzz.cpp)
+    GL_REQUIRE(d.num_selectors <= GL_MAX_GATES && d.cap_height <= 16 && d.num_query_rounds <= num_bytes / 8 && d.num_public_inputs <= num_bytes / 8,
+               GL_ERR_ARG, "gl_verify: a count of the description exceeds what the proof bytes can hold");
     for (unsigned g = 0; g < d.num_gates; g++)
         GL_REQUIRE(d.gate_types[g] <= glhost::G_LAST && d.gate_selector_index[g] < d.num_selectors && d.gate_group_start[g] <= g && g < d.gate_group_end[g] && d.gate_group_end[g] <= d.num_gates,
                    GL_ERR_ARG, "gl_verify: bad gate / selector description");

@@ -101,6 +101,31 @@ def test_verifier_under_address_and_ub_sanitizers(orc, tmp_path):
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
 
 
+def test_circuit_data_reader_and_descriptions_under_address_and_ub_sanitizers(orc, tmp_path):
+    # gl_common_data_from_bytes / gl_verify_bytes parse untrusted CIRCUIT DATA, and gl_verify / gl_common_data_to_bytes index with every
+    # count of a caller-filled description: the host code rebuilt with -fsanitize=address,undefined (tools/sanitizer/data_fuzz.cpp) gets
+    # the VerifierCircuitData bytes of the all-gates circuit (two lookup tables, 11 gate types) with 3000 mutations (bit flips,
+    # truncations, huge and plausible counts, garbage, inserted bytes) and 3000 mutated descriptions.  (The first run of this harness
+    # found gl_verify sizing a vector by an unbounded num_query_rounds.)
+    import os, subprocess
+    from plonky2_demo_amd import api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    oc = orc.circuit_of_kind(15, 9, threads=4)
+    w = oc.witness(np.array([200, 300], dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=2)
+    desc = oc.product_desc()
+    cap, dig = np.ascontiguousarray(oc.constants_sigmas_cap), np.ascontiguousarray(oc.digest)
+    (tmp_path / "vd.bin").write_bytes(api.verifier_data_to_bytes(desc, cap, dig))
+    (tmp_path / "proof.bin").write_bytes(w.prove(threads=4).to_bytes())
+    (tmp_path / "desc.bin").write_bytes(bytes(desc))
+    (tmp_path / "cap.bin").write_bytes(cap.tobytes())
+    (tmp_path / "dig.bin").write_bytes(dig.tobytes())
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tools", "sanitizer"), "data_fuzz"])
+    r = subprocess.run([os.path.join(root, "tools", "sanitizer", "data_fuzz"), str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "valid: 0" in r.stdout and "description mutations:" in r.stdout
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
 @pytest.mark.parametrize("kind,param", [(1, 16), (1, 5), (1, 40), (2, 50), (2, 400)])
 def test_other_circuit_shapes_over_the_same_gate_set(orc, kind, param):
     # circuits the matmul family never produces (oracle/gl_circuit.hpp build_test_circuit): no ArithmeticGate, or no Poseidon
