@@ -747,18 +747,23 @@ class CircuitView:
 
     def __init__(self, circuit_data, ctx):
         self.cd, self.ctx = circuit_data, ctx
+        self.n = 1 << circuit_data.desc.degree_bits          # CircuitData and GenericCircuitData both carry the description
 
     def prove_device(self, d_wires_ptr, public_inputs, public_inputs_hash=None):
-        return _prove_device(self.ctx, self.cd.handle, self.cd.host.n, d_wires_ptr, public_inputs, public_inputs_hash)
+        return _prove_device(self.ctx, self.cd.handle, self.n, d_wires_ptr, public_inputs, public_inputs_hash)
 
     def prove(self, wires, public_inputs):
         wires, pis = _u64(wires), _u64(public_inputs)
+        if wires.shape != (135, self.n):
+            raise ValueError("wire matrix must be [135][n]")
+        if pis.size == 0:
+            pis = np.zeros(1, dtype=np.uint64)[:0]
         h = ctypes.c_void_p()
         check(lib.gl_prove(self.ctx.handle, self.cd.handle, _p(wires), _p(pis), pis.size, ctypes.byref(h)))
-        return Proof(h.value, self.cd.host.n)
+        return Proof(h.value, self.n)
 
     def prove_columns(self, columns, public_inputs):
-        return _prove_columns(self.ctx, self.cd.handle, self.cd.host.n, columns, public_inputs)
+        return _prove_columns(self.ctx, self.cd.handle, self.n, columns, public_inputs)
 
 
 class FriProver:

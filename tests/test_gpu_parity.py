@@ -670,6 +670,38 @@ def test_concurrent_proofs_on_shared_circuit_are_deterministic(gpu):
         assert by == wits[k][2], (lane, rep, k)
 
 
+def test_concurrent_proofs_of_a_circuit_with_lookups_on_six_lanes(gpu, orc):
+    # the all-gates circuit (two lookup tables, exponentiation, range check, ...; its own launches: k_lookup_inverses / k_lookup_scan per
+    # table, k_quotient_lookup) proved from six host threads on six contexts against ONE device-resident circuit, from HOST wire matrices
+    # (the pinned H2D ring per context): every proof equals the oracle's bytes for its witness
+    import threading
+    p, ctx = gpu
+    oc = orc.circuit_of_kind(15, 9, threads=8)
+    cd = p.GenericCircuitData(oc.product_desc(), oc.constants_sigmas())
+    wits = []
+    for k, (x, y) in enumerate(((200, 300), (0, 0), (255, 511))):
+        w = oc.witness(np.array([x, y], dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=k)
+        wits.append((w.wires(), w.public_inputs(), w.prove(threads=8).to_bytes()))
+    lanes = [p.api.CircuitView(cd, ctx)] + [p.api.CircuitView(cd, p.Context(device=0)) for _ in range(5)]
+    results, errors = {}, []
+
+    def work(lane):
+        try:
+            for rep in range(3):
+                for k, (wires, pis, _) in enumerate(wits):
+                    results[(lane, rep, k)] = lanes[lane].prove(wires, pis).to_bytes()
+        except Exception as e:
+            errors.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors
+    assert len(results) == 6 * 3 * 3
+    for (lane, rep, k), by in results.items():
+        assert by == wits[k][2], (lane, rep, k)
+
+
 def test_host_witness_entry_on_eight_lanes_equals_prove_device(gpu):
     # the drop-in entry (plonk/prover.rs:145 -> gl_prove_columns): 64 proofs of the m = 64 circuit from HOST
     # witness matrices -- 135 separate pageable vectors each, as MatrixWitness.wire_values holds them (iop/witness.rs:256-258) -- on 8
