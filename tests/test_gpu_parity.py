@@ -441,6 +441,29 @@ def test_prove_m128_config5(gpu, orc):
     assert len(pr.challenges()["fri_betas"]) == 4
 
 
+def test_prove_m256_the_largest_size_the_abi_takes(gpu):
+    # m = 256: n = 2^21 rows, LDE 2^24 = the ABI's limit (degree_bits + rate_bits <= 24; two-pass NTT of 2^12 x 2^12 with tiles that span
+    # several waves, 2.3 GB of witness through the pinned H2D ring, four arity-16 FRI rounds down to a 32-coefficient final polynomial, 1.77 MB proof).  No CPU prover at this size:
+    # the native verifier accepts the bytes, rejects a flipped one, the witness spot-checks against the product of the matrices.
+    p, ctx = gpu
+    m = 256
+    hc = p.MatmulCircuit(m)
+    assert hc.degree_bits == 21 and hc.desc.num_fri_rounds == 4
+    rng = np.random.default_rng(256)
+    a = rng.integers(0, 2**32 - 1, m * m, dtype=np.uint64)
+    b = rng.integers(0, 2**32 - 1, m * m, dtype=np.uint64)
+    wires, pis = hc.witness(a, b, filler_seed=256)
+    c = sum(int(a[200 * m + k]) * int(b[k * m + 31]) for k in range(m)) % P
+    assert int(pis[3 * (200 * m + 31) + 2]) == c
+    cd = hc.build()
+    pr = cd.prove(wires, pis)
+    by = pr.to_bytes()
+    assert len(by) == 1774624 and cd.verify(pr) == (True, "")
+    bad = bytearray(by); bad[len(by) // 2] ^= 4
+    assert not cd.verify(bytes(bad))[0]
+    assert len(pr.challenges()["fri_betas"]) == 4
+
+
 # ------------------------------------------------------------------------------- phase-level ABI (SURVEY 8b seam)
 class _ProductChallenger:
     """The same interface over the library's own gl_challenger_* (for callers without a transcript implementation)."""
