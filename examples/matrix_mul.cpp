@@ -42,6 +42,8 @@ int main(int argc, char** argv) {
     CHECK(gl_ctx_create(0, nullptr, &ctx));
     gl_circuit* circuit = nullptr;
     CHECK(gl_circuit_from_host(ctx, hc, &circuit));
+    CHECK(gl_circuit_warm_up(ctx, circuit));          // part of build(): kernels loaded, twiddle tables built, pool sized (the reference
+                                                      // precomputes its fft_root_table in build() as well, circuit_builder.rs:1016-1019)
     const size_t n = size_t(1) << desc.degree_bits, ncap = size_t(1) << desc.cap_height;
     std::vector<uint64_t> cap(4 * ncap), digest(4);
     CHECK(gl_circuit_constants_sigmas_cap(circuit, cap.data()));

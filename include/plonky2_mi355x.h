@@ -241,6 +241,10 @@ int gl_host_circuit_wire_classes(const gl_host_circuit* hc, uint64_t* h_out);
  * first_lut_row from the lookup selector columns (they are ProverOnlyCircuitData::lookup_rows in the reference and are not part of
  * CommonCircuitData's bytes), checks any the caller named against them, and refuses a mismatch with GL_ERR_ARG. */
 int gl_circuit_description(const gl_circuit* c, gl_circuit_desc* out);
+/* Optional, once per (context, circuit) before the first proof: one pass of the proving pipeline over a zero witness, thrown away,
+ * so that the first gl_prove on this context does not pay for loading the kernels' code objects, building the twiddle tables of the
+ * circuit's transform sizes and growing the context's pool (m = 64: 15 ms for the first proof without it, 7 ms with). */
+int gl_circuit_warm_up(gl_ctx* ctx, const gl_circuit* c);
 int gl_circuit_digest(const gl_circuit* c, uint64_t h_out[4]);                 /* verifier_only.circuit_digest */
 int gl_circuit_constants_sigmas_cap(const gl_circuit* c, uint64_t* h_out);     /* [2^cap_height][4]            */
 const gl_batch* gl_circuit_constants_sigmas_batch(const gl_circuit* c);

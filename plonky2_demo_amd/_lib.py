@@ -93,6 +93,7 @@ SIGNATURES = {
     "gl_circuit_create": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "gl_circuit_from_host": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "gl_circuit_description": (c_int, [c_vp, c_vp]),
+    "gl_circuit_warm_up": (c_int, [c_vp, c_vp]),
     "gl_circuit_digest": (c_int, [c_vp, c_vp]),
     "gl_circuit_constants_sigmas_cap": (c_int, [c_vp, c_vp]),
     "gl_circuit_constants_sigmas_batch": (c_vp, [c_vp]),

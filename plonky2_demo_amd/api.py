@@ -491,9 +491,19 @@ def _prove_columns(ctx, circuit_handle, n, columns, public_inputs):
     return Proof(h.value, n)
 
 
+def _warm_up(ctx, handle):
+    check(lib.gl_circuit_warm_up(ctx.handle, handle))
+
+
 class _PhaseApi:
     """The phase-level seam of a device-resident circuit, for a caller that owns the Challenger; `self.desc` is the
     gl_circuit_desc, `self.handle` the gl_circuit.  Circuits with the lookup argument pass the 8 delta challenges."""
+
+    def warm_up(self, ctx=None):
+        """gl_circuit_warm_up: one throw-away pass of the proving pipeline on `ctx` (default: the circuit's context), so that the first
+        proof does not pay the one-time costs (kernel code objects, twiddle tables, pool growth)."""
+        _warm_up(_ctx(ctx) if ctx is not None else self.ctx, self.handle)
+        return self
 
     def _batch(self, handle, ctx):
         return PolynomialBatch(handle, ctx, self.desc.rate_bits, self.desc.cap_height)

@@ -865,6 +865,23 @@ extern "C" int gl_prove_device_hashed(gl_ctx* ctx, const gl_circuit* cir, const 
     GL_REQUIRE(public_inputs_hash, GL_ERR_ARG, "gl_prove_device_hashed: null hash");
     return prove_impl(ctx, cir, d_wires, true, h_pis, npis, public_inputs_hash, out);
 }
+// One pass of the proving pipeline over an all-zero witness, result thrown away: afterwards this context holds everything a proof of this
+// circuit needs besides its own data -- the code objects of every kernel on the path loaded, the twiddle / power tables of the circuit's
+// transform sizes built, the context's pool grown to the pipeline's working set.  (The reference precomputes its fft_root_table in build()
+// too, circuit_builder.rs:1016-1019.)  A zero witness does not satisfy the circuit; nothing on the path asserts that it does.
+extern "C" int gl_circuit_warm_up(gl_ctx* ctx, const gl_circuit* cir) {
+    GL_REQUIRE(ctx && cir, GL_ERR_ARG, "gl_circuit_warm_up: null argument");
+    GL_REQUIRE(cir->ctx->device == ctx->device, GL_ERR_ARG, "gl_circuit_warm_up: circuit lives on another device");
+    GL_TRY(ctx->activate());
+    const size_t n = cir->n;
+    DevBuf d_w(ctx); GL_TRY(d_w.alloc(135 * n * sizeof(gl_t)));
+    GL_CHECK_HIP(hipMemsetAsync(d_w.p, 0, 135 * n * sizeof(gl_t), ctx->stream));
+    std::vector<uint64_t> pis(cir->desc.num_public_inputs ? cir->desc.num_public_inputs : 1, 0);
+    gl_proof* pr = nullptr;
+    const int st = prove_impl(ctx, cir, d_w.as<uint64_t>(), true, pis.data(), cir->desc.num_public_inputs, nullptr, &pr);
+    if (pr) gl_proof_free(pr);
+    return st == GL_ERR_ZETA_IN_SUBGROUP ? GL_OK : st;       // (probability 2^-49: still warmed up to the opening point)
+}
 static int prove_impl(gl_ctx* ctx, const gl_circuit* cir, const uint64_t* h_wires, bool wires_on_device, const uint64_t* h_pis, size_t npis, const uint64_t* h_pi_hash, gl_proof** out) {
     GL_REQUIRE(ctx && cir && h_wires && h_pis && out, GL_ERR_ARG, "gl_prove: null argument");
     // circuit data is read-only while proving: any context (stream) of the same device may prove against it

@@ -441,6 +441,28 @@ def test_prove_m128_config5(gpu, orc):
     assert len(pr.challenges()["fri_betas"]) == 4
 
 
+def test_warm_up_leaves_proofs_unchanged_and_takes_the_one_time_costs(gpu, orc):
+    # gl_circuit_warm_up: a throw-away pass of the pipeline on a zero witness (which does not satisfy the circuit: nothing asserts it).
+    # On a FRESH context the proof after it equals the proof without it byte for byte; for a lookup circuit too.
+    import time
+    p, ctx = gpu
+    m = 32
+    hc = p.MatmulCircuit(m)
+    a, b = rand_field(1, m * m) % (2**32 - 1), rand_field(2, m * m) % (2**32 - 1)
+    wires, pis = hc.witness(a, b, filler_seed=3)
+    want = hc.build(ctx).prove(wires, pis).to_bytes()
+    c2 = p.Context(device=0)
+    cd2 = hc.build(c2).warm_up()
+    t0 = time.perf_counter(); got = cd2.prove(wires, pis).to_bytes(); t_first = time.perf_counter() - t0
+    t0 = time.perf_counter(); again = cd2.prove(wires, pis).to_bytes(); t_second = time.perf_counter() - t0
+    assert got == want and again == want
+    assert t_first < 3 * t_second + 0.005, (t_first, t_second)          # the first proof is no longer the slow one
+    oc = orc.circuit_of_kind(10, 2, threads=8)
+    w = oc.witness(np.array([3, 200, 17, 255], dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=5)
+    cd3 = p.GenericCircuitData(oc.product_desc(), oc.constants_sigmas(), ctx=p.Context(device=0)).warm_up()
+    assert cd3.prove(w.wires(), w.public_inputs()).to_bytes() == w.prove(threads=8).to_bytes()
+
+
 def test_prove_m256_the_largest_size_the_abi_takes(gpu):
     # m = 256: n = 2^21 rows, LDE 2^24 = the ABI's limit (degree_bits + rate_bits <= 24; two-pass NTT of 2^12 x 2^12 with tiles that span
     # several waves, 2.3 GB of witness through the pinned H2D ring, four arity-16 FRI rounds down to a 32-coefficient final polynomial, 1.77 MB proof).  No CPU prover at this size:
