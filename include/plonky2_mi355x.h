@@ -340,6 +340,13 @@ const gl_circuit* gl_prover_pool_circuit(const gl_prover_pool* p);     /* for gl
 /* a[i], b[i]: row-major m x m operands on the host; filler_seeds may be null (seed i); out_proofs[count] */
 int gl_prover_pool_prove_matmul(gl_prover_pool* p, size_t count, const uint64_t* const* a, const uint64_t* const* b,
                                 const uint64_t* filler_seeds, gl_proof** out_proofs);
+/* The pool for ANY circuit the library proves (what gl_circuit_create takes), every lane warmed up (gl_circuit_warm_up), and `count`
+ * proofs from HOST witnesses on it: columns[i][j] = wire column j (n values) of witness i, as MatrixWitness.wire_values holds them
+ * (iop/witness.rs:256-258), public_inputs[i] = its num_public_inputs values; item i goes through gl_prove_columns on lane i % lanes.
+ * The batch analogue of the INTEGRATION.md section-3 patch: a Rayon `par_iter` over witnesses becomes one call. */
+int gl_prover_pool_create_generic(int device, const gl_circuit_desc* desc, const uint64_t* h_constants_sigmas, uint32_t lanes, gl_prover_pool** out);
+int gl_prover_pool_prove_columns(gl_prover_pool* p, size_t count, const uint64_t* const* const* columns, const uint64_t* const* public_inputs,
+                                 gl_proof** out_proofs);
 void gl_prover_pool_free(gl_prover_pool* p);
 
 /* ProofWithPublicInputs::to_bytes (plonk/proof.rs:104-110; util/serialization/mod.rs:1939-1981) */

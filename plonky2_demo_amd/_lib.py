@@ -94,6 +94,8 @@ SIGNATURES = {
     "gl_circuit_from_host": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp)]),
     "gl_circuit_description": (c_int, [c_vp, c_vp]),
     "gl_circuit_warm_up": (c_int, [c_vp, c_vp]),
+    "gl_prover_pool_create_generic": (c_int, [c_int, c_vp, c_vp, c_u32, ctypes.POINTER(c_vp)]),
+    "gl_prover_pool_prove_columns": (c_int, [c_vp, c_sz, c_vp, c_vp, c_vp]),
     "gl_circuit_digest": (c_int, [c_vp, c_vp]),
     "gl_circuit_constants_sigmas_cap": (c_int, [c_vp, c_vp]),
     "gl_circuit_constants_sigmas_batch": (c_vp, [c_vp]),

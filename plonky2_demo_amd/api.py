@@ -708,6 +708,52 @@ def verify_bytes(verifier_data, proof_bytes):
     check(st)
 
 
+class GenericProverPool:
+    """gl_prover_pool_create_generic / _prove_columns: `lanes` warmed-up contexts and host threads inside the library for ANY circuit
+    (description + constants || sigmas); a batch of host witnesses (135 column vectors each) becomes one call."""
+
+    def __init__(self, desc, constants_sigmas, lanes=4, device=0):
+        self.desc, self.n = desc, 1 << desc.degree_bits
+        cs = _u64(constants_sigmas)
+        if cs.shape != (desc.num_constants + 80, self.n):
+            raise ValueError("constants_sigmas must be [num_constants + 80][n]")
+        h = ctypes.c_void_p()
+        check(lib.gl_prover_pool_create_generic(device, ctypes.byref(desc), _p(cs), lanes, ctypes.byref(h)))
+        self.handle = h.value
+
+    def prove_columns(self, witnesses):
+        """witnesses: list of (columns, public_inputs), columns = 135 arrays of n u64 (or a [135][n] matrix); returns the Proofs in order."""
+        k = len(witnesses)
+        keep, col_ptrs, pi_ptrs = [], (ctypes.c_void_p * k)(), (ctypes.c_void_p * k)()
+        for i, (cols, pis) in enumerate(witnesses):
+            cols = [np.ascontiguousarray(_u64(c).reshape(-1)) for c in cols]
+            if len(cols) != 135 or any(c.size != self.n for c in cols):
+                raise ValueError("a witness is 135 columns of n values")
+            arr = (ctypes.c_void_p * 135)(*[c.ctypes.data for c in cols])
+            pv = np.ascontiguousarray(_u64(pis).reshape(-1))
+            if pv.size != self.desc.num_public_inputs:
+                raise ValueError("wrong number of public inputs")
+            keep.append((cols, arr, pv))
+            col_ptrs[i] = ctypes.addressof(arr)
+            pi_ptrs[i] = pv.ctypes.data if pv.size else None
+        out = (ctypes.c_void_p * k)()
+        st = lib.gl_prover_pool_prove_columns(self.handle, k, col_ptrs, pi_ptrs, out)
+        proofs = [Proof(out[i], self.n) if out[i] else None for i in range(k)]
+        check(st)
+        return proofs
+
+    def close(self):
+        if self.handle:
+            lib.gl_prover_pool_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ProverPool:
     """Many proofs in flight on one GPU from one call (gl_prover_pool_*): one circuit, `lanes` streams and host threads in C++."""
 

@@ -178,6 +178,55 @@ extern "C" void gl_prover_pool_free(gl_prover_pool* p) {
     delete p;
 }
 
+// The same pool for ANY circuit the library proves (a description + the constants || sigmas value columns, as gl_circuit_create takes
+// them): no witness generators, the witnesses come from the host (gl_prover_pool_prove_columns).  Every lane is warmed up.
+extern "C" int gl_prover_pool_create_generic(int device, const gl_circuit_desc* desc, const uint64_t* h_constants_sigmas, uint32_t lanes, gl_prover_pool** out) {
+    GL_REQUIRE(desc && h_constants_sigmas && out && lanes >= 1 && lanes <= 64, GL_ERR_ARG, "gl_prover_pool_create_generic: bad argument (1..64 lanes)");
+    std::unique_ptr<gl_prover_pool, void (*)(gl_prover_pool*)> p(new gl_prover_pool(), gl_prover_pool_free);
+    p->device = device;
+    for (uint32_t k = 0; k < lanes; k++) {
+        gl_ctx* c = nullptr;
+        GL_TRY(gl_ctx_create(device, nullptr, &c));
+        p->ctxs.push_back(c);
+    }
+    GL_TRY(gl_circuit_create(p->ctxs[0], desc, h_constants_sigmas, &p->circuit));
+    for (uint32_t k = 0; k < lanes; k++) GL_TRY(gl_circuit_warm_up(p->ctxs[k], p->circuit));
+    *out = p.release();
+    return GL_OK;
+}
+
+// count proofs from HOST witnesses: columns[i][j] = wire column j (n values) of witness i, as MatrixWitness.wire_values holds them
+// (iop/witness.rs:256-258); public_inputs[i] = its num_public_inputs values.  Item i is proved on lane i % lanes through gl_prove_columns
+// (the lane's pinned H2D ring).  out_proofs[i] receives a gl_proof; returns the first error of any lane (the other proofs stay valid).
+extern "C" int gl_prover_pool_prove_columns(gl_prover_pool* p, size_t count, const uint64_t* const* const* columns, const uint64_t* const* public_inputs,
+                                            gl_proof** out_proofs) {
+    GL_REQUIRE(p && p->circuit && (count == 0 || (columns && public_inputs && out_proofs)), GL_ERR_ARG, "gl_prover_pool_prove_columns: null argument");
+    for (size_t i = 0; i < count; i++) out_proofs[i] = nullptr;
+    gl_circuit_desc d;
+    GL_TRY(gl_circuit_description(p->circuit, &d));
+    const size_t lanes = p->ctxs.size(), npis = d.num_public_inputs;
+    std::atomic<int> first_error{GL_OK};
+    std::vector<std::string> messages(lanes);
+    const uint64_t none = 0;
+    auto work = [&](size_t lane) {
+        for (size_t i = lane; i < count && first_error.load() == GL_OK; i += lanes) {
+            int st = (columns[i] && (public_inputs[i] || npis == 0)) ? GL_OK : GL_ERR_ARG;
+            if (st == GL_OK) st = gl_prove_columns(p->ctxs[lane], p->circuit, columns[i], npis ? public_inputs[i] : &none, npis, &out_proofs[i]);
+            if (st != GL_OK) { int expected = GL_OK; messages[lane] = st == GL_ERR_ARG && !columns[i] ? "gl_prover_pool_prove_columns: null witness" : gl_last_error(); first_error.compare_exchange_strong(expected, st); }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (size_t k = 1; k < lanes && k < count; k++) threads.emplace_back(work, k);
+    work(0);
+    for (auto& t : threads) t.join();
+    const int st = first_error.load();
+    if (st != GL_OK) {
+        for (auto& m : messages) if (!m.empty()) return gl_fail(st, m.c_str(), __FILE__, __LINE__);
+        return gl_fail(st, "gl_prover_pool_prove_columns: a lane failed", __FILE__, __LINE__);
+    }
+    return GL_OK;
+}
+
 extern "C" int gl_prover_pool_create(int device, const gl_host_circuit* hc, uint32_t lanes, gl_prover_pool** out) {
     GL_REQUIRE(hc && out && lanes >= 1 && lanes <= 64, GL_ERR_ARG, "gl_prover_pool_create: bad argument (1..64 lanes)");
     std::unique_ptr<gl_prover_pool, void (*)(gl_prover_pool*)> p(new gl_prover_pool(), gl_prover_pool_free);
@@ -209,6 +258,7 @@ extern "C" const gl_circuit* gl_prover_pool_circuit(const gl_prover_pool* p) { r
 extern "C" int gl_prover_pool_prove_matmul(gl_prover_pool* p, size_t count, const uint64_t* const* a, const uint64_t* const* b,
                                            const uint64_t* filler_seeds, gl_proof** out_proofs) {
     GL_REQUIRE(p && (count == 0 || (a && b && out_proofs)), GL_ERR_ARG, "gl_prover_pool_prove_matmul: null argument");
+    GL_REQUIRE(p->hc, GL_ERR_ARG, "gl_prover_pool_prove_matmul: this pool was created for a generic circuit (gl_prover_pool_prove_columns)");
     for (size_t i = 0; i < count; i++) out_proofs[i] = nullptr;
     const size_t lanes = p->ctxs.size(), npis = 3 * p->hc->hc.m * p->hc->hc.m;
     std::atomic<int> first_error{GL_OK};

@@ -747,6 +747,38 @@ def test_concurrent_proofs_of_a_circuit_with_lookups_on_six_lanes(gpu, orc):
         assert by == wits[k][2], (lane, rep, k)
 
 
+def test_generic_prover_pool_proves_a_batch_of_host_witnesses(gpu, orc):
+    # gl_prover_pool_create_generic / gl_prover_pool_prove_columns: six warmed-up lanes inside the library for the all-gates circuit and for
+    # a Merkle-proof circuit; a batch of 20 host witnesses (135 separate column vectors each) in one call; every proof == the oracle's
+    from test_verifier import merkle_proof_circuit_inputs
+    p, ctx = gpu
+    oc = orc.circuit_of_kind(15, 9, threads=8)
+    pool = p.api.GenericProverPool(oc.product_desc(), oc.constants_sigmas(), lanes=6)
+    wits, want = [], []
+    for k in range(20):
+        w = oc.witness(np.array([(37 * k) % 256, (91 * k) % 512], dtype=np.uint64), np.zeros(0, dtype=np.uint64), filler_seed=k)
+        wires = w.wires()
+        wits.append(([wires[j].copy() for j in range(135)], w.public_inputs()))
+        want.append(w.prove(threads=8).to_bytes())
+    got = pool.prove_columns(wits)
+    assert [g.to_bytes() for g in got] == want
+    assert pool.prove_columns([]) == []
+    from plonky2_demo_amd._lib import lib, check
+    with pytest.raises(p.Plonky2Mi355xError):
+        check(lib.gl_prover_pool_prove_matmul(pool.handle, 0, None, None, None, None))      # a generic pool has no matmul witness generators
+    pool.close()
+    oc2 = orc.circuit_of_kind(14, 6, threads=8)
+    pool2 = p.api.GenericProverPool(oc2.product_desc(), oc2.constants_sigmas(), lanes=3)
+    wits, want = [], []
+    for idx in (0, 21, 63, 42):
+        a, _root = merkle_proof_circuit_inputs(orc, 6, idx)
+        w = oc2.witness(a, np.zeros(0, dtype=np.uint64), filler_seed=idx)
+        wits.append((w.wires(), w.public_inputs()))
+        want.append(w.prove(threads=8).to_bytes())
+    assert [g.to_bytes() for g in pool2.prove_columns(wits)] == want
+    pool2.close()
+
+
 def test_host_witness_entry_on_eight_lanes_equals_prove_device(gpu):
     # the drop-in entry (plonk/prover.rs:145 -> gl_prove_columns): 64 proofs of the m = 64 circuit from HOST
     # witness matrices -- 135 separate pageable vectors each, as MatrixWitness.wire_values holds them (iop/witness.rs:256-258) -- on 8
