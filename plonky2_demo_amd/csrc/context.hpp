@@ -188,3 +188,13 @@ struct gl_batch {
     GlMerkle tree;
     size_t N() const { return n << rate_bits; }
 };
+
+// RAII block from a context's stream-ordered pool
+struct DevBuf {
+    gl_ctx* c; void* p = nullptr;
+    explicit DevBuf(gl_ctx* ctx) : c(ctx) {}
+    int alloc(size_t bytes) { return c->pool_alloc(bytes, &p); }
+    void release() { if (p) { c->pool_release(p); p = nullptr; } }
+    ~DevBuf() { release(); }
+    template <class T> T* as() const { return (T*)p; }
+};

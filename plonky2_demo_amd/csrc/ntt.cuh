@@ -34,6 +34,9 @@
 #define NTT_WAVES_PER_SIMD (NTT_THREADS / 64 / 4 * 2)  // two workgroups per CU (LDS)
 #endif
 #define NTT_LOCAL_MAX_LOG 12            // largest in-LDS transform
+#ifndef NTT_NESTED_MIN_LOG
+#define NTT_NESTED_MIN_LOG 23           // from 2^23 points on: three passes (2^10 x a two-pass M) instead of two with 2^12-point tiles
+#endif
 #ifndef NTT_COL_DIRECT
 #define NTT_COL_DIRECT 1
 #endif
@@ -63,6 +66,10 @@ struct NttPassParams {
     const gl_t* pre_lo; const gl_t* pre_hi;    // optional input scale by s^i (two-level), or null
     const gl_t* post_lo; const gl_t* post_hi;  // optional output scale by c*s^k (two-level), or null
     gl_t post_const;                   // scalar output factor when post tables are null (1 = none)
+    uint32_t out_shift;                // row pass of a NESTED transform (N = 2^out_shift x M, this pass finishes the M-point rows): batch entry
+                                       // b is outer row (b & (2^out_shift - 1)) of polynomial b >> out_shift and output k of it goes to
+                                       // (k << out_shift) + outer row.  A tile then holds ONE inner row (blockIdx.x) of T consecutive batch
+                                       // entries (blockIdx.y * T ..), so that its scattered stores are T-element segments as well.
 #ifdef NTT_ABLATION
     uint32_t debug;                    // diagnostic builds only (-DNTT_ABLATION, env GL_NTT_DEBUG): 1 skip stages, 2 skip loads, 4 skip stores
 #endif
@@ -493,10 +500,15 @@ __device__ __forceinline__ void ntt_row_tile(const NttPassParams& p, gl_t* lds, 
     constexpr bool single = SINGLE;                         // == (p.lgN1 == 0)
     uint32_t tile = bx;
     if (!single && (gridDim.x & 7) == 0) tile = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
-    const uint32_t r0 = tile << LOGT;                       // first row (k1) or first polynomial
-    const uint32_t b = single ? 0 : by;
+    const uint32_t out_shift = single ? 0 : p.out_shift;
+    const bool nested = out_shift != 0;
+    const uint32_t r0 = nested ? 0 : tile << LOGT;          // first row (k1) or first polynomial
+    const uint32_t b = single ? 0 : (nested ? by << LOGT : by);        // (first) batch entry of the tile
     const gl_t* src = p.src + (uint64_t)b * p.src_stride;
-    gl_t* dst = p.dst + (uint64_t)b * p.dst_stride;
+    gl_t* dst = p.dst + (uint64_t)(b >> out_shift) * p.dst_stride;
+    // row t of the tile starts at element row_off + (t << row_shift) of src, and its output k2 goes to k_off + t + (k2 << k_shift)
+    const uint32_t row_shift = nested ? p.lgN1 + p.lgN2 : LOGL, row_off = nested ? tile << LOGL : r0 << LOGL;
+    const uint32_t k_shift = p.lgN1 + out_shift, k_off = nested ? (tile << out_shift) + (b & ((1u << out_shift) - 1u)) : r0;
     if constexpr (G::WAVE_OWNED && !SINGLE && !NTT_ABLATION_BUILD) {
         // second pass over wave-owned rows: every wave reads its own rows (contiguous, canonical: the column pass wrote them)
         // straight into the registers of the first radix stage
@@ -504,7 +516,7 @@ __device__ __forceinline__ void ntt_row_tile(const NttPassParams& p, gl_t* lds, 
         // table words are there long before the rows): after it the waves of the workgroup run independently up to the final transpose.
         ntt_fill_lds_twiddles<LOGL>(lds, p.tw_local, tid);
         ntt_first_stage_direct<LOGL, INV, false, false>(lds, tid,
-            [&](int t, int i2) -> gl_t { return ntt_ld(src, ((r0 + (uint32_t)t) << LOGL) + (uint32_t)i2); },
+            [&](int t, int i2) -> gl_t { return ntt_ld(src, row_off + ((uint32_t)t << row_shift) + (uint32_t)i2); },
             [](int, int, gl_t v) -> gl_t { return v; },
             [] { __syncthreads(); });
         ntt_wave_sync();
@@ -520,7 +532,7 @@ __device__ __forceinline__ void ntt_row_tile(const NttPassParams& p, gl_t* lds, 
             const uint32_t poly = r0 + r;
             v[q] = (poly < p.batch && i2 < p.n_in) ? p.src[(uint64_t)poly * p.src_stride + i2] : 0;
         } else {
-            v[q] = NTT_DBG(p, 2) ? (gl_t)e : ntt_ld(src, ((r0 + r) << LOGL) + i2);
+            v[q] = NTT_DBG(p, 2) ? (gl_t)e : ntt_ld(src, row_off + (r << row_shift) + i2);
         }
     }
 #pragma unroll
@@ -554,13 +566,12 @@ __device__ __forceinline__ void ntt_row_tile(const NttPassParams& p, gl_t* lds, 
             }
         }
     } else {
-        const uint32_t lgN1 = p.lgN1;
         // store X[k1 + N1*k2]: e -> (k2 = e / T, r = e % T): T-element segments
 #pragma unroll 4
         for (int q = 0; q < NTT_EPT; q++) {
             const int e = tid + NTT_THREADS * q;
             const uint32_t r = e & (T - 1), k2 = e >> LOGT;
-            const uint32_t k = (r0 + r) + (k2 << lgN1);
+            const uint32_t k = k_off + r + (k2 << k_shift);
             gl_t x = lds[G::at(r, k2)];
             if (p.post_lo) x = glx_mul<true>(x, ntt_pow2level(p.post_lo, p.post_hi, k));
             else if (p.post_const != 1) x = glx_mul<true>(x, p.post_const);

@@ -166,10 +166,56 @@ int gl_ntt_run(gl_ctx* c, const gl_t* src, uint64_t src_stride, uint32_t n_in, g
         const uint32_t T = 1u << (NTT_TILE_LOG - lgN);
         return dispatch_row(c, (int)lgN, inverse, p, dim3((batch + T - 1) / T, 1));
     }
-    const uint32_t lgN1 = lgN / 2, lgN2 = lgN - lgN1;
     gl_t w = gl_host_root_of_unity(lgN);
     if (inverse) w = gl_canon(gl_inv(w));
     GL_TRY(c->get_pow_table(w, 1, (uint32_t)(N >> NTT_SPLIT_LOG), &tw));
+    if (lgN >= NTT_NESTED_MIN_LOG) {
+        // THREE passes, N = 2^10 x M: a column pass over the 2^10-point columns (stride M) with the twiddles w_N^(i2 k1), then the
+        // M-point rows as a two-pass transform of their own whose row pass scatters output q of row k1 to k1 + 2^10 q.  Every pass has
+        // columns of at most 2^10 points (tiles a wave owns); the 2^12-point tiles of the two-pass split run at 40 % of that rate.
+        const uint32_t lgA = 10, lgM = lgN - lgA, lgM1 = lgM / 2, lgM2 = lgM - lgM1;
+        const uint64_t M = uint64_t(1) << lgM;
+        gl_t wm = gl_host_root_of_unity(lgM);
+        if (inverse) wm = gl_canon(gl_inv(wm));
+        GlPowTable twm;
+        GL_TRY(c->get_pow_table(wm, 1, (uint32_t)(M >> NTT_SPLIT_LOG), &twm));
+        gl_t row_post_const = gl_canon(post_const);
+        const gl_t* twm_pass = nullptr;
+        GL_TRY(c->get_pass_table(wm, post_shift ? gl_t(1) : row_post_const, lgM1, lgM2, &twm_pass));      // the scalar factor rides in the table
+        if (!post_shift) row_post_const = 1;
+        size_t want = c->scratch_target > N ? c->scratch_target : N;
+        if (want > (size_t)batch * N) want = (size_t)batch * N;
+        GL_TRY(c->ensure_scratch(want));
+        uint32_t chunk_max = (uint32_t)(c->scratch_elems >> lgN);
+        if (chunk_max > (65535u >> lgA)) chunk_max = 65535u >> lgA;                // the inner passes index rows through gridDim.y
+        DevBuf second(c);
+        GL_TRY(second.alloc(((size_t)(batch < chunk_max ? batch : chunk_max) << lgN) * sizeof(gl_t)));
+        const uint32_t TA = 1u << (NTT_TILE_LOG - lgA), TB = 1u << (NTT_TILE_LOG - lgM1), TC = 1u << (NTT_TILE_LOG - lgM2);
+        for (uint32_t b0 = 0; b0 < batch; b0 += chunk_max) {
+            const uint32_t nb = (batch - b0) < chunk_max ? (batch - b0) : chunk_max;
+            NttPassParams a = p;                                                    // columns of 2^10 points, stride M
+            a.src = src + (uint64_t)b0 * src_stride; a.src_stride = src_stride;
+            a.dst = c->scratch; a.dst_stride = N;
+            a.batch = nb; a.lgN1 = lgA; a.lgN2 = lgM; a.n_in = n_in;
+            a.tw_lo = tw.lo; a.tw_hi = tw.hi;
+            if (pre_shift) { a.pre_lo = pre.lo; a.pre_hi = pre.hi; }
+            GL_TRY(dispatch_col(c, (int)lgA, inverse, a, dim3((uint32_t)(M / TA), nb)));
+            NttPassParams ic = p;                                                   // the rows (nb x 2^10 of them, contiguous): their column pass
+            ic.src = c->scratch; ic.src_stride = M;
+            ic.dst = second.as<gl_t>(); ic.dst_stride = M;
+            ic.batch = nb << lgA; ic.lgN1 = lgM1; ic.lgN2 = lgM2; ic.n_in = (uint32_t)M;
+            ic.tw_lo = twm.lo; ic.tw_hi = twm.hi; ic.tw_pass = twm_pass;
+            GL_TRY(dispatch_col(c, (int)lgM1, inverse, ic, dim3((1u << lgM2) / TB, nb << lgA)));
+            NttPassParams ir = p;                                                   // ... and their row pass, scattering into the result
+            ir.src = second.as<gl_t>(); ir.src_stride = M;
+            ir.dst = dst + (uint64_t)b0 * dst_stride; ir.dst_stride = dst_stride;
+            ir.batch = nb << lgA; ir.lgN1 = lgM1; ir.lgN2 = lgM2; ir.n_in = (uint32_t)M; ir.out_shift = lgA;
+            if (post_shift) { ir.post_lo = post.lo; ir.post_hi = post.hi; } else ir.post_const = row_post_const;
+            GL_TRY(dispatch_row(c, (int)lgM2, inverse, ir, dim3(1u << lgM1, (nb << lgA) / TC)));      // a tile: one inner row of TC outer rows
+        }
+        return GL_OK;
+    }
+    const uint32_t lgN1 = lgN / 2, lgN2 = lgN - lgN1;
     // the N inter-pass twiddles as a table in output order (8 N bytes, shared by every polynomial of every batch): worth it
     // when several polynomials share it
     const gl_t* tw_pass = nullptr;

@@ -29,15 +29,6 @@ struct gl_proof {
     std::vector<uint64_t> query_indices;
 };
 
-struct DevBuf {                     // RAII block from the context's stream-ordered pool
-    gl_ctx* c; void* p = nullptr;
-    explicit DevBuf(gl_ctx* ctx) : c(ctx) {}
-    int alloc(size_t bytes) { return c->pool_alloc(bytes, &p); }
-    void release() { if (p) { c->pool_release(p); p = nullptr; } }
-    ~DevBuf() { release(); }
-    template <class T> T* as() const { return (T*)p; }
-};
-
 // ---- host Challenger (iop/challenger.rs:30-153) -----------------------------------------------------------------
 struct HostChallenger {
     gl_t state[12]; gl_t in[8]; int nin = 0; gl_t out[8]; int nout = 0;

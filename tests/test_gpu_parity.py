@@ -188,6 +188,31 @@ def test_ntt_large_sizes_round_trip(gpu, orc):
             assert (f == orc.fft(x)).all()
 
 
+@pytest.mark.parametrize("lg", [23, 24])
+def test_ntt_three_pass_sizes_against_the_oracle(gpu, orc, lg):
+    # from 2^23 points on the transform is nested: 2^10-point columns, then the M-point rows as a two-pass transform whose row pass
+    # scatters into the result (ntt.hip gl_ntt_run).  Forward, inverse, coset forms, the LDE with its zero padding, a batch that needs
+    # two chunks of the inter-pass scratch: all against the oracle's radix-2 transforms.
+    p, ctx = gpu
+    x = rand_field(900 + lg, (2, 1 << lg))
+    f = p.fft(x)
+    assert (f == orc.fft(x)).all()
+    assert (p.ifft(f) == x).all()
+    assert (p.ifft(x[:1]) == orc.ifft(x[:1])).all()
+    s = 0x123456789ABCDEF % P
+    assert (p.coset_fft(x[:1], s) == orc.coset_fft(x[:1], s)).all()
+    assert (p.coset_ifft(x[:1], 7) == orc.coset_ifft(x[:1], 7)).all()
+    c = rand_field(950 + lg, (2, 1 << (lg - 3)))
+    assert (p.lde_onto_coset(c, 3) == orc.lde(c, 3, threads=8)).all()
+    ctx.set_scratch_elems(1 << lg)                      # one polynomial per chunk
+    try:
+        y = rand_field(990 + lg, (3, 1 << lg))
+        fy = p.fft(y)
+        assert (fy[2] == orc.fft(y[2:3])[0]).all() and (fy[0] == p.fft(y[0:1])[0]).all()
+    finally:
+        ctx.set_scratch_elems(1 << 24)
+
+
 def test_ntt_chunked_batches(gpu, orc):
     # more polynomials than fit the inter-pass scratch: exercises the chunk loop
     p, ctx = gpu
