@@ -36,6 +36,7 @@
 #define NTT_LOCAL_MAX_LOG 12            // largest in-LDS transform
 #ifndef NTT_NESTED_MIN_LOG
 #define NTT_NESTED_MIN_LOG 23           // from 2^23 points on: three passes (2^10 x a two-pass M) instead of two with 2^12-point tiles
+                                        // (the smallest size the nesting fits: the rows' column pass needs 2^13 / 2^(lgM / 2) <= 2^(lgM - lgM / 2) columns)
 #endif
 #ifndef NTT_COL_DIRECT
 #define NTT_COL_DIRECT 1
