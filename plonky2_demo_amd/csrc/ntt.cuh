@@ -35,8 +35,8 @@
 #endif
 #define NTT_LOCAL_MAX_LOG 12            // largest in-LDS transform
 #ifndef NTT_NESTED_MIN_LOG
-#define NTT_NESTED_MIN_LOG 23           // from 2^23 points on: three passes (2^10 x a two-pass M) instead of two with 2^12-point tiles
-                                        // (the smallest size the nesting fits: the rows' column pass needs 2^13 / 2^(lgM / 2) <= 2^(lgM - lgM / 2) columns)
+#define NTT_NESTED_MIN_LOG 22           // from 2^22 points on: three passes (2^9 or 2^10-point columns x a two-pass M >= 2^13) instead of two
+                                        // with 2^11 / 2^12-point tiles (M >= 2^13: the rows' column pass needs a full tile of columns)
 #endif
 #ifndef NTT_COL_DIRECT
 #define NTT_COL_DIRECT 1

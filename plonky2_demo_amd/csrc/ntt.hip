@@ -169,12 +169,12 @@ int gl_ntt_run(gl_ctx* c, const gl_t* src, uint64_t src_stride, uint32_t n_in, g
     gl_t w = gl_host_root_of_unity(lgN);
     if (inverse) w = gl_canon(gl_inv(w));
     GL_TRY(c->get_pow_table(w, 1, (uint32_t)(N >> NTT_SPLIT_LOG), &tw));
-    static_assert(NTT_NESTED_MIN_LOG >= 23, "the nested split needs M = N / 2^10 >= 2^13 (a full tile of columns in the rows' column pass)");
+    static_assert(NTT_NESTED_MIN_LOG >= 22, "the nested split needs M >= 2^13 (a full tile of columns in the rows' column pass) and columns of >= 2^9 points");
     if (lgN >= NTT_NESTED_MIN_LOG) {
         // THREE passes, N = 2^10 x M: a column pass over the 2^10-point columns (stride M) with the twiddles w_N^(i2 k1), then the
         // M-point rows as a two-pass transform of their own whose row pass scatters output q of row k1 to k1 + 2^10 q.  Every pass has
         // columns of at most 2^10 points (tiles a wave owns); the 2^12-point tiles of the two-pass split run at 40 % of that rate.
-        const uint32_t lgA = 10, lgM = lgN - lgA, lgM1 = lgM / 2, lgM2 = lgM - lgM1;
+        const uint32_t lgA = lgN >= 23 ? 10 : lgN - 13, lgM = lgN - lgA, lgM1 = lgM / 2, lgM2 = lgM - lgM1;
         const uint64_t M = uint64_t(1) << lgM;
         gl_t wm = gl_host_root_of_unity(lgM);
         if (inverse) wm = gl_canon(gl_inv(wm));

@@ -188,9 +188,9 @@ def test_ntt_large_sizes_round_trip(gpu, orc):
             assert (f == orc.fft(x)).all()
 
 
-@pytest.mark.parametrize("lg", [23, 24])
+@pytest.mark.parametrize("lg", [22, 23, 24])
 def test_ntt_three_pass_sizes_against_the_oracle(gpu, orc, lg):
-    # from 2^23 points on the transform is nested: 2^10-point columns, then the M-point rows as a two-pass transform whose row pass
+    # from 2^22 points on the transform is nested: 2^9 / 2^10-point columns, then the M-point rows as a two-pass transform whose row pass
     # scatters into the result (ntt.hip gl_ntt_run).  Forward, inverse, coset forms, the LDE with its zero padding, a batch that needs
     # two chunks of the inter-pass scratch: all against the oracle's radix-2 transforms.
     p, ctx = gpu
