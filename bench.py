@@ -254,7 +254,7 @@ def ntt_leg(torch, ctx, lib, check, dev, batch, with_rows=True):
     ctx.synchronize()
     dt = time.perf_counter() - t0
     intact = bool(torch.equal(data, ref))
-    rep = timed_launches(ctx, lambda: check(lib.gl_ntt_forward(ctx.handle, ptr, LOG_N, batch)), reps, run_in=2 * reps)
+    rep = timed_launches(ctx, lambda: check(lib.gl_ntt_forward(ctx.handle, ptr, LOG_N, batch)), reps, run_in=4 * reps)
     fwd_ms = sum(v["ms"] for v in rep.values()) / reps
     launches = {k: {"per_ntt": v["count"] / reps, "avg_ms": round(v["ms"] / v["count"], 5)} for k, v in rep.items()}
     algo = 16.0 * L * batch
