@@ -399,7 +399,7 @@ static int lookup_polys_values(gl_ctx* ctx, const gl_circuit* cir, const gl_t* d
     hipStream_t st = ctx->stream;
     uint32_t max_rows = 0;
     for (unsigned t = 0; t < d.num_luts; t++) max_rows = std::max(max_rows, d.first_lut_row[t] - d.last_lu_row[t] + 1);
-    DevBuf d_inv(ctx); GL_TRY(d_inv.alloc((size_t)2 * max_rows * 64 * sizeof(gl_t)));
+    DevBuf d_agg(ctx); GL_TRY(d_agg.alloc((size_t)2 * max_rows * 8 * sizeof(gl_t)));
     gl_t dl[8]; for (int i = 0; i < 8; i++) dl[i] = gl_canon(deltas8[i]);
     ctx->timing_begin("compute lookup polys");
     GL_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)2 * d.num_lookup_polys * n * sizeof(gl_t), st));
@@ -408,9 +408,10 @@ static int lookup_polys_values(gl_ctx* ctx, const gl_circuit* cir, const gl_t* d
     for (unsigned t = 0; t < d.num_luts; t++) {
         const uint32_t nrows = d.first_lut_row[t] - d.last_lu_row[t] + 1;
         hipLaunchKernelGGL(k_lookup_inverses, dim3(nrows, 2), dim3(64), 0, st, d_wires, (uint32_t)n, d.last_lu_row[t], d.last_lut_row[t],
-                           dl[glhost::LU_CH_A], dl[glhost::LU_CH_ALPHA], dl[4 + glhost::LU_CH_A], dl[4 + glhost::LU_CH_ALPHA], d_inv.as<gl_t>());
-        hipLaunchKernelGGL(k_lookup_scan, dim3(1), dim3(64), 0, st, d_wires, (uint32_t)n, d.last_lu_row[t], d.last_lut_row[t], d.first_lut_row[t],
-                           dl[glhost::LU_CH_B], dl[glhost::LU_CH_DELTA], dl[4 + glhost::LU_CH_B], dl[4 + glhost::LU_CH_DELTA], d_inv.as<const gl_t>(), d_out);
+                           dl[glhost::LU_CH_A], dl[glhost::LU_CH_ALPHA], dl[glhost::LU_CH_B], dl[glhost::LU_CH_DELTA],
+                           dl[4 + glhost::LU_CH_A], dl[4 + glhost::LU_CH_ALPHA], dl[4 + glhost::LU_CH_B], dl[4 + glhost::LU_CH_DELTA], d_agg.as<gl_t>());
+        hipLaunchKernelGGL(k_lookup_scan, dim3(1), dim3(64), 0, st, (uint32_t)n, d.last_lu_row[t], d.last_lut_row[t], d.first_lut_row[t],
+                           dl[glhost::LU_CH_DELTA], dl[4 + glhost::LU_CH_DELTA], d_agg.as<const gl_t>(), d_out);
     }
     ctx->timing_end();
     GL_CHECK_HIP(hipGetLastError());

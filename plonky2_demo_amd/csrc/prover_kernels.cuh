@@ -553,55 +553,63 @@ __global__ __launch_bounds__(256) void k_quotient_random_access(GlQuotParams p) 
     p.out[N + i] = glx_add_cc(p.out[N + i], o1);
 }
 
-// compute_lookup_polys (plonk/prover.rs:425-541).  Step 1: 1 / (alpha - (inp + a out)) for every slot of every lookup row, in parallel:
-// grid = (rows from last_lu_row to first_lut_row, 2 challenges), block = 64 (slot = thread).  inv[ch][row - last_lu_row][64]
+// compute_lookup_polys (plonk/prover.rs:425-541).  Step 1, in parallel over the lookup rows: grid = (rows from last_lu_row to first_lut_row,
+// 2 challenges), block = 64 (slot = thread).  Per row and challenge it leaves eight words agg[ch][row - last_lu_row][8]:
+//   [0]     table rows: sum_s (inp_s + b out_s) delta^(25 - s), the row's contribution to RE (RE[row] = RE[row + 1] delta^26 + this)
+//   [1..6]  the row's six partial sums: table rows sum_{s in group} mult_s / (alpha - (inp_s + a out_s)) over groups of 5 slots,
+//           LookupGate rows sum_{s in group} 1 / (alpha - (inp_s + a out_s)) over groups of 7 slots
+// so that the sequential step 2 reads 8 words per row instead of 78 wires (sums in F_p are exact in any order).
 __global__ __launch_bounds__(64) void k_lookup_inverses(const gl_t* __restrict__ wires, uint32_t n, uint32_t last_lu_row, uint32_t last_lut_row,
-                                                        gl_t a0, gl_t alpha0, gl_t a1, gl_t alpha1, gl_t* __restrict__ inv) {
+                                                        gl_t a0, gl_t alpha0, gl_t b0, gl_t delta0, gl_t a1, gl_t alpha1, gl_t b1, gl_t delta1,
+                                                        gl_t* __restrict__ agg) {
+    __shared__ gl_t term[64], re_term[64];
     const uint32_t row = last_lu_row + blockIdx.x, ch = blockIdx.y, sl = threadIdx.x;
     const bool table_row = row >= last_lut_row;
-    const uint32_t nslots = table_row ? 26u : 40u, stride = table_row ? 3u : 2u;
-    gl_t v = 0;
+    const uint32_t nslots = table_row ? 26u : 40u, stride = table_row ? 3u : 2u, group = table_row ? 5u : 7u;
+    gl_t v = 0, rt = 0;
     if (sl < nslots) {
         const gl_t inp = wires[(size_t)(stride * sl) * n + row], outv = wires[(size_t)(stride * sl + 1) * n + row];
         const gl_t a = ch ? a1 : a0, alpha = ch ? alpha1 : alpha0;
-        v = gl_canon(gl_inv(gl_sub(alpha, gl_add(inp, gl_mul(a, outv)))));
+        v = gl_inv(gl_sub(alpha, gl_add(inp, gl_mul(a, outv))));
+        if (table_row) {
+            v = gl_mul(v, wires[(size_t)(3 * sl + 2) * n + row]);                                      // multiplicity / (alpha - combo)
+            rt = gl_mul(gl_add(inp, gl_mul(ch ? b1 : b0, outv)), gl_exp(ch ? delta1 : delta0, 25u - sl));
+        }
     }
-    inv[((size_t)ch * gridDim.x + blockIdx.x) * 64 + sl] = v;
+    term[sl] = v; re_term[sl] = rt;
+    __syncthreads();
+    gl_t* o = agg + ((size_t)ch * gridDim.x + blockIdx.x) * 8;
+    if (sl == 0) { gl_t s = 0; for (uint32_t k = 0; k < 26; k++) s = gl_add(s, re_term[k]); o[0] = gl_canon(s); }
+    if (sl >= 1 && sl <= 6) {
+        const uint32_t s0 = (sl - 1) * group, s1 = (s0 + group < nslots) ? s0 + group : nslots;
+        gl_t s = 0;
+        for (uint32_t k = s0; k < s1; k++) s = gl_add(s, term[k]);
+        o[sl] = gl_canon(s);
+    }
 }
-// Step 2: the running sums, sequential over the (few) rows: thread c = challenge c.  Writes the 7 columns of its challenge (RE, 6 partial
-// SLDC), which the caller zeroed: out[(7 c + k) * n + row].
-__global__ void k_lookup_scan(const gl_t* __restrict__ wires, uint32_t n, uint32_t last_lu_row, uint32_t last_lut_row, uint32_t first_lut_row,
-                              gl_t b0, gl_t delta0, gl_t b1, gl_t delta1, const gl_t* __restrict__ inv, gl_t* __restrict__ out) {
+// Step 2: the running sums, sequential over the (few) rows: thread c = challenge c, eight aggregate words per row.  Writes the 7
+// columns of its challenge (RE, 6 partial SLDC), which the caller zeroed: out[(7 c + k) * n + row].
+__global__ void k_lookup_scan(uint32_t n, uint32_t last_lu_row, uint32_t last_lut_row, uint32_t first_lut_row,
+                              gl_t delta0, gl_t delta1, const gl_t* __restrict__ agg, gl_t* __restrict__ out) {
     const uint32_t c = threadIdx.x;
     if (c >= 2) return;
-    const gl_t cb = c ? b1 : b0, cdelta = c ? delta1 : delta0;
+    const gl_t d26 = gl_exp(c ? delta1 : delta0, 26);
     const uint32_t nrows = first_lut_row - last_lu_row + 1;
-    const gl_t* iv = inv + (size_t)c * nrows * 64;
+    const gl_t* ag = agg + (size_t)c * nrows * 8;
     gl_t* o = out + (size_t)(7 * c) * n;
     gl_t re_next = 0, last_next = 0;                           // RE and the last partial polynomial on the row above (0 above the first table row)
     for (uint32_t row = first_lut_row + 1; row-- > last_lut_row;) {          // partial Sums and RE, from the first table row down
-        const gl_t* r = iv + (size_t)(row - last_lu_row) * 64;
-        gl_t re = re_next;
-        for (uint32_t sl = 0; sl < 26; sl++) re = gl_add(gl_mul(re, cdelta), gl_add(wires[(size_t)(3 * sl) * n + row], gl_mul(cb, wires[(size_t)(3 * sl + 1) * n + row])));
+        const gl_t* r = ag + (size_t)(row - last_lu_row) * 8;
+        const gl_t re = gl_add(gl_mul(re_next, d26), r[0]);
         o[row] = gl_canon(re); re_next = re;
         gl_t sum = last_next;
-        for (uint32_t slot = 0; slot < 6; slot++) {
-            const uint32_t s0 = slot * 5, s1 = (s0 + 5 < 26) ? s0 + 5 : 26;
-            for (uint32_t sl = s0; sl < s1; sl++) sum = gl_add(sum, gl_mul(wires[(size_t)(3 * sl + 2) * n + row], r[sl]));
-            o[(size_t)(slot + 1) * n + row] = gl_canon(sum);
-        }
+        for (uint32_t slot = 0; slot < 6; slot++) { sum = gl_add(sum, r[1 + slot]); o[(size_t)(slot + 1) * n + row] = gl_canon(sum); }
         last_next = sum;
     }
     for (uint32_t row = last_lut_row; row-- > last_lu_row;) {                // partial LDCs
-        const gl_t* r = iv + (size_t)(row - last_lu_row) * 64;
+        const gl_t* r = ag + (size_t)(row - last_lu_row) * 8;
         gl_t cur = last_next;
-        for (uint32_t slot = 0; slot < 6; slot++) {
-            const uint32_t s0 = slot * 7, s1 = (s0 + 7 < 40) ? s0 + 7 : 40;
-            gl_t sum = 0;
-            for (uint32_t sl = s0; sl < s1; sl++) sum = gl_add(sum, r[sl]);
-            cur = gl_sub(cur, sum);
-            o[(size_t)(slot + 1) * n + row] = gl_canon(cur);
-        }
+        for (uint32_t slot = 0; slot < 6; slot++) { cur = gl_sub(cur, r[1 + slot]); o[(size_t)(slot + 1) * n + row] = gl_canon(cur); }
         last_next = cur;
     }
 }

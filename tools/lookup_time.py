@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Device time of the lookup-polynomial phase (compute_all_lookup_polys: k_lookup_inverses + the single-thread k_lookup_scan per table)
 next to the whole proof, for circuits with one and two 256-entry tables:  python tools/lookup_time.py
-(MI355X, round 3: 0.13-0.25 ms of a 2.4-2.7 ms proof at n = 2^7..2^9; the scan walks the ~35-100 lookup rows serially, ~3 us per row)"""
+(MI355X, round 3: 0.03-0.06 ms of a 2.3-2.6 ms proof at n = 2^7..2^9 -- 0.13-0.25 ms while the serial scan read all 78 wires of a row
+itself; the per-row sums are now taken in parallel by k_lookup_inverses and the scan reads 8 words per row)"""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
