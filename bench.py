@@ -195,7 +195,7 @@ def cpu_baseline(m, rows=False, one_thread_full=False):
         t0 = time.perf_counter(); p1 = w.prove(threads=1); t_full1 = time.perf_counter() - t0
         measured_1t = {"value": 1.0 / t_full1, "unit": "proofs/s", "seconds": round(t_full1, 2), "verifies": bool(p1.verify()[0])}
     return {
-        "value": 1.0 / med, "unit": "proofs/s", "cores": cores, "threads": threads, "cpu_quota_cores": cpu_quota_cores(), "kind": "port", "micro_kernel_rows": micro, "one_thread_measured": measured_1t,
+        "value": 1.0 / med, "unit": "proofs/s", "cores": threads, "threads": threads, "cores_affinity": cores, "cpu_quota_cores": cpu_quota_cores(), "kind": "port", "micro_kernel_rows": micro, "one_thread_measured": measured_1t,
         "runs_s": [round(t, 3) for t in times],
         "one_thread": committed_one_thread(m),
         "sample": "all cores: median of %d full proofs (after one warm-up proof) of the m=%d circuit by the C++ restatement of the reference prover (oracle/gl_prover.hpp), "
