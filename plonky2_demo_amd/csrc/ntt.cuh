@@ -78,7 +78,12 @@ struct NttPassParams {
 
 __host__ __device__ constexpr int ntt_first_radix(int rem) {
     if (NTT_EPT >= 32) return rem <= 5 ? rem : (rem == 6) ? 3 : (rem == 7 || rem == 8) ? 4 : 5;     // radix at most 32: 10 = 5 + 5
+    // 2^10 = 16 x 16 x 4 (round 3, late; 16 x 8 x 8 before, -DNTT_PLAN_16_8_8): 3/4 instead of 7/8 of the last stage's inputs carry a
+    // general twiddle and a task loads 3 instead of 7 of them: 0.577 -> 0.566 ms for the 2^20 x 64 transform
+#ifdef NTT_PLAN_16_8_8
     if (NTT_EPT >= 16) return rem <= 4 ? rem : (rem == 5 || rem == 6 || rem == 9) ? 3 : 4;
+#endif
+    if (NTT_EPT >= 16) return rem <= 4 ? rem : (rem == 5 || rem == 9) ? 3 : 4;
     return rem <= 3 ? rem : (rem == 4 ? 2 : 3);          // radix at most 8: 10 = 3 + 3 + 2 + 2
 }
 __host__ __device__ constexpr unsigned ntt_bitrev(unsigned x, int bits) {
