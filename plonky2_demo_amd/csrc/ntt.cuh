@@ -83,7 +83,7 @@ __host__ __device__ constexpr int ntt_first_radix(int rem) {
 #ifdef NTT_PLAN_16_8_8
     if (NTT_EPT >= 16) return rem <= 4 ? rem : (rem == 5 || rem == 6 || rem == 9) ? 3 : 4;
 #endif
-    if (NTT_EPT >= 16) return rem <= 4 ? rem : (rem == 5 || rem == 9) ? 3 : 4;
+    if (NTT_EPT >= 16) return rem <= 4 ? rem : (rem == 5) ? 3 : 4;         // 2^9 = 16 x 8 x 4 (8 x 16 x 4 before: 0.1445 -> 0.1409 ms for 2^18 x 64)
     return rem <= 3 ? rem : (rem == 4 ? 2 : 3);          // radix at most 8: 10 = 3 + 3 + 2 + 2
 }
 __host__ __device__ constexpr unsigned ntt_bitrev(unsigned x, int bits) {
